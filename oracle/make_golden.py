@@ -1,0 +1,280 @@
+"""Generate tests/golden/*.safetensors by running the REFERENCE sampler in the build container.
+
+Run here only (needs /root/reference and `transformers`; neither exists on the GPU box):
+
+    python -m oracle.make_golden            # from the repo root
+
+What runs, and whose code it is:
+  * ``src.sampling.sample`` and ``src.diffusion.utils.configure_schedule`` are imported from
+    /root/reference and run unmodified (they import only torch).
+  * the decoder is ``transformers.BertModel(BertConfig(is_decoder=True, add_cross_attention=True))``
+    and the encoder ``transformers`` ``BlenderbotEncoder`` / ``BertModel`` built from config, as
+    reference ``get_components`` does minus the hub download (src/diffusion/model.py:29-54).
+    ``attn_implementation="eager"`` is chosen because the reference pins transformers 4.30.2,
+    whose only path was eager; the sdpa path is also run and its deviation printed.
+  * ``src.diffusion.model`` itself is not importable here (ModuleNotFoundError: lightning), so
+    ``RefShapedDiDi`` below restates DiDi.__init__'s sampler-visible attributes (model.py:104-127)
+    and DiDi.forward (model.py:165-198) as a plain nn.Module around those HF modules.
+  * the noise stream is CAPTURED from the reference run by recording what ``torch.randn_like``
+    and ``Tensor.normal_`` return while ``sample`` runs.
+
+Every fixture is data only: weights, inputs, the captured noise, the denoiser inputs x_t of every
+call, the returned context, final logits and ids.  TEST INFRASTRUCTURE: see oracle/__init__.py.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import torch
+from safetensors.torch import save_file
+from torch import nn
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+class RefShapedDiDi(nn.Module):
+    def __init__(self, encoder, decoder, enc_dim, dec_dim, vocab, *, diffusion_steps, schedule, pad_idx=0,
+                 tie_weights=False, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf")):
+        super().__init__()
+        from src.diffusion.utils import configure_schedule  # the reference's own schedule code
+
+        self.diffusion_steps = diffusion_steps
+        self.encoder_dim, self.decoder_dim = enc_dim, dec_dim
+        self.emb = nn.Embedding(vocab, dec_dim, padding_idx=pad_idx)
+        self.time_embeds = nn.Embedding(diffusion_steps + 1, dec_dim)
+        self.s_churn, self.s_tmin, self.s_tmax = s_churn, s_tmin, s_tmax
+        self.encoder, self.decoder = encoder, decoder
+        self.classifier = nn.Linear(dec_dim, vocab, bias=False)
+        if tie_weights:
+            self.classifier.weight = self.emb.weight
+        if enc_dim != dec_dim:
+            self.adapter = nn.Sequential(nn.Linear(enc_dim, dec_dim), nn.Tanh(), nn.Linear(dec_dim, dec_dim))
+        sigmas, std_0 = configure_schedule(diffusion_steps, schedule)
+        self.register_buffer("sigmas", sigmas)
+        self.register_buffer("std_0", std_0)
+        self.calls = []  # decoder_inputs_embeds of every call, in order
+
+    def forward(self, encoder_input_ids=None, encoder_attention_mask=None, decoder_inputs_embeds=None,
+                time_ids=None, context=None):
+        if encoder_input_ids is None and context is None:
+            raise ValueError("Either `encoder_input_ids` or `context` must be provided.")
+        if context is None:
+            context = self.encoder(input_ids=encoder_input_ids, attention_mask=encoder_attention_mask).last_hidden_state
+            if self.encoder_dim != self.decoder_dim:
+                context = self.adapter(context)
+        self.calls.append(decoder_inputs_embeds.detach().clone())
+        x = decoder_inputs_embeds + self.time_embeds(time_ids)
+        out = self.decoder(inputs_embeds=x, encoder_hidden_states=context,
+                           encoder_attention_mask=encoder_attention_mask).last_hidden_state
+        return out, context
+
+
+class Ctx:
+    def __init__(self, ids, mask):
+        self.input_ids, self.attention_mask = ids, mask
+
+
+class NoiseTap:
+    """Record every tensor the global generator hands to the reference sampler."""
+
+    def __enter__(self):
+        self.draws = []
+        self._randn_like, self._normal_ = torch.randn_like, torch.Tensor.normal_
+        tap = self
+
+        def randn_like(x, *a, **k):
+            r = tap._randn_like(x, *a, **k)
+            tap.draws.append(r.detach().clone())
+            return r
+
+        def normal_(self_t, *a, **k):
+            r = tap._normal_(self_t, *a, **k)
+            tap.draws.append(self_t.detach().clone())
+            return r
+
+        torch.randn_like, torch.Tensor.normal_ = randn_like, normal_
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like, torch.Tensor.normal_ = self._randn_like, self._normal_
+
+
+def build_model(spec, seed, attn="eager"):
+    from transformers import BertConfig, BertModel, BlenderbotConfig
+    from transformers.models.blenderbot.modeling_blenderbot import BlenderbotEncoder
+
+    torch.manual_seed(seed)
+    V = spec["vocab"]
+    if spec["enc_kind"] == "blenderbot":
+        ecfg = BlenderbotConfig(vocab_size=V, d_model=spec["enc_dim"], encoder_layers=spec["enc_layers"],
+                                encoder_attention_heads=spec["enc_heads"], encoder_ffn_dim=spec["enc_ffn"],
+                                decoder_layers=1, decoder_attention_heads=spec["enc_heads"], decoder_ffn_dim=8,
+                                max_position_embeddings=128, scale_embedding=True, activation_function="gelu",
+                                dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, pad_token_id=0,
+                                attn_implementation=attn)
+        encoder = BlenderbotEncoder(ecfg)
+    else:
+        ecfg = BertConfig(vocab_size=V, hidden_size=spec["enc_dim"], num_hidden_layers=spec["enc_layers"],
+                          num_attention_heads=spec["enc_heads"], intermediate_size=spec["enc_ffn"],
+                          hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation=attn)
+        encoder = BertModel(ecfg)
+    dcfg = BertConfig(vocab_size=V, is_decoder=True, add_cross_attention=True, hidden_size=spec["dec_dim"],
+                      num_hidden_layers=spec["dec_layers"], num_attention_heads=spec["dec_heads"],
+                      intermediate_size=spec["dec_ffn"], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                      attn_implementation=attn)
+    decoder = BertModel(dcfg)
+    model = RefShapedDiDi(encoder, decoder, spec["enc_dim"], spec["dec_dim"], V,
+                          diffusion_steps=spec["T"], schedule=spec["schedule"],
+                          s_churn=spec.get("s_churn", 0.0), s_tmin=spec.get("s_tmin", 0.0),
+                          s_tmax=spec.get("s_tmax", float("inf")))
+    # LayerNorm/bias perturbation so that gamma/beta/bias paths are actually exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("LayerNorm.weight") or n.endswith("layer_norm.weight"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            elif n.endswith(".bias"):
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+    return model.eval()
+
+
+def make_inputs(B, C, V, seed, min_len=2):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, V, (B, C), generator=g)
+    lens = torch.randint(min_len, C + 1, (B,), generator=g)
+    lens[0] = C  # one full row
+    mask = (torch.arange(C)[None, :] < lens[:, None]).long()
+    ids = ids * mask  # pad id 0, right padding (commonsense_dataset.py:27-32 pads to max_length)
+    return ids, mask
+
+
+def run_case(model, ids, mask, mode, step_freq, max_len, noise_seed, noise_factor=1):
+    from src.sampling import sample  # the reference sampler, unmodified
+
+    model.calls.clear()
+    torch.manual_seed(noise_seed)
+    with NoiseTap() as tap:
+        logits = sample(Ctx(ids, mask), model, mode, step_freq, noise_factor=noise_factor,
+                        max_len=max_len, raw_output=True)
+    return logits, tap.draws, list(model.calls)
+
+
+def sd_hash(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+TINY = dict(vocab=600, enc_kind="blenderbot", enc_dim=96, enc_layers=2, enc_heads=4, enc_ffn=256,
+            dec_dim=128, dec_layers=2, dec_heads=4, dec_ffn=512, T=20, schedule="sqrt")
+TINY_BERT = dict(vocab=600, enc_kind="bert", enc_dim=128, enc_layers=2, enc_heads=4, enc_ffn=256,
+                 dec_dim=128, dec_layers=2, dec_heads=4, dec_ffn=512, T=10, schedule="cosine")
+CONFIG1 = dict(vocab=8008, enc_kind="blenderbot", enc_dim=128, enc_layers=2, enc_heads=4, enc_ffn=512,
+               dec_dim=128, dec_layers=2, dec_heads=4, dec_ffn=512, T=50, schedule="sqrt")
+
+
+def state_dict_of(model):
+    return {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
+
+
+def save_case(name, spec, run, logits, draws, calls, ctx, ids, mask, extra_meta=None, weights=None):
+    t = {"in.input_ids": ids, "in.attention_mask": mask, "out.logits": logits.contiguous(),
+         "out.ids": logits.argmax(-1), "out.context": ctx.contiguous()}
+    for i, d in enumerate(draws):
+        t[f"noise.{i}"] = d.contiguous()
+    for i, c in enumerate(calls):
+        t[f"xt.{i}"] = c.contiguous()
+    if weights is not None:
+        for k, v in weights.items():
+            t["w." + k] = v
+    meta = {"spec": json.dumps(spec), "run": json.dumps(run), "n_noise": str(len(draws)), "n_calls": str(len(calls))}
+    meta.update(extra_meta or {})
+    save_file(t, os.path.join(OUT, name + ".safetensors"), metadata=meta)
+    print(f"wrote {name}: {len(draws)} draws, {len(calls)} calls, logits {tuple(logits.shape)}")
+
+
+def main():
+    sys.path.insert(0, REF)
+    os.makedirs(OUT, exist_ok=True)
+    from src.diffusion.utils import configure_schedule
+
+    # (F) schedules, straight from the reference
+    t = {}
+    for sched in ("sqrt", "cosine", "linear"):
+        for T in (50, 2000):
+            s, std0 = configure_schedule(T, sched)
+            t[f"{sched}.{T}.sigmas"] = s.contiguous()
+            t[f"{sched}.{T}.std_0"] = std0.reshape(1).contiguous()
+    save_file(t, os.path.join(OUT, "schedules.safetensors"))
+
+    # (A-D) tiny blenderbot-encoder model; weights stored once
+    model = build_model(TINY, seed=11)
+    w = state_dict_of(model)
+    save_file({"w." + k: v for k, v in w.items()}, os.path.join(OUT, "tiny_weights.safetensors"),
+              metadata={"spec": json.dumps(TINY), "sha256": sd_hash(w)})
+    ids, mask = make_inputs(4, 12, TINY["vocab"], seed=5)
+    cases = [
+        ("tiny_ddpm_f1", dict(mode="ddpm", step_freq=1, max_len=-1, noise_seed=101), {}),
+        ("tiny_ddpm_f3_len8", dict(mode="ddpm", step_freq=3, max_len=8, noise_seed=102), {}),
+        ("tiny_euler_f2", dict(mode="euler", step_freq=2, max_len=-1, noise_seed=103), {}),
+        ("tiny_euler_churn_f4", dict(mode="euler", step_freq=4, max_len=-1, noise_seed=104),
+         dict(s_churn=1.5, s_tmin=0.5, s_tmax=50.0)),
+    ]
+    for name, run, euler_kw in cases:
+        for k in ("s_churn", "s_tmin", "s_tmax"):
+            setattr(model, k, euler_kw.get(k, {"s_churn": 0.0, "s_tmin": 0.0, "s_tmax": float("inf")}[k]))
+        logits, draws, calls = run_case(model, ids, mask, run["mode"], run["step_freq"], run["max_len"], run["noise_seed"])
+        ctx = model(encoder_input_ids=ids, encoder_attention_mask=mask, decoder_inputs_embeds=calls[0],
+                    time_ids=torch.ones(ids.shape[0], 1, dtype=torch.long))[1]
+        save_case(name, dict(TINY, **euler_kw), run, logits, draws, calls, ctx.detach(), ids, mask)
+    # eager vs sdpa deviation on the first case (information only)
+    m2 = build_model(TINY, seed=11, attn="sdpa")
+    l_e, _, _ = run_case(build_model(TINY, seed=11), ids, mask, "ddpm", 1, -1, 101)
+    l_s, _, _ = run_case(m2, ids, mask, "ddpm", 1, -1, 101)
+    print("eager vs sdpa max|dlogits| =", (l_e - l_s).abs().max().item(),
+          "ids equal:", bool((l_e.argmax(-1) == l_s.argmax(-1)).all()))
+
+    # (E) bert-encoder variant (enc_dim == dec_dim -> no adapter), weights inside the case file
+    mb = build_model(TINY_BERT, seed=12)
+    ids_b, mask_b = make_inputs(3, 9, TINY_BERT["vocab"], seed=6)
+    run = dict(mode="ddpm", step_freq=2, max_len=-1, noise_seed=105)
+    logits, draws, calls = run_case(mb, ids_b, mask_b, **{k: run[k] for k in ("mode", "step_freq", "max_len", "noise_seed")})
+    ctx = mb(encoder_input_ids=ids_b, encoder_attention_mask=mask_b, decoder_inputs_embeds=calls[0],
+             time_ids=torch.ones(3, 1, dtype=torch.long))[1]
+    save_case("tiny_bertenc_ddpm_f2", TINY_BERT, run, logits, draws, calls, ctx.detach(), ids_b, mask_b,
+              weights=state_dict_of(mb))
+
+    # (G) BASELINE config 1 (V=8008, T=50, B=8, C=24): weights are NOT stored (13 MB); they are
+    # regenerated from the seed by tests/golden_util.py:config1_state_dict and checked by sha256.
+    sys.path.insert(0, os.path.dirname(OUT))
+    from golden_util import config1_inputs, config1_state_dict
+
+    w1 = config1_state_dict()
+    m1 = build_model(CONFIG1, seed=0)
+    missing, unexpected = m1.load_state_dict(w1, strict=False)
+    assert not unexpected, unexpected
+    assert all(("position_ids" in k or "token_type_ids" in k or "word_embeddings" in k or "pooler" in k) for k in missing), missing
+    ids1, mask1 = config1_inputs()
+    run = dict(mode="ddpm", step_freq=1, max_len=-1, noise_seed=0xBADB01)
+    logits, draws, calls = run_case(m1, ids1, mask1, "ddpm", 1, -1, 0xBADB01)
+    keep = [0, 1, 10, 25, 40, 49]
+    t = {"in.input_ids": ids1, "in.attention_mask": mask1, "out.ids": logits.argmax(-1),
+         "out.logits_b0": logits[0].contiguous(), "noise.0": draws[0].contiguous()}
+    for i in keep:
+        t[f"xt.{i}"] = calls[i].contiguous()
+    # the noise stream is the plain global-generator sequence: prove it, so tests may regenerate it
+    torch.manual_seed(0xBADB01)
+    regen = [torch.randn(draws[0].shape)] + [torch.empty(draws[0].shape).normal_(0, 1) for _ in draws[1:]]
+    assert all(torch.equal(a, b) for a, b in zip(regen, draws))
+    save_file(t, os.path.join(OUT, "config1_ddpm.safetensors"),
+              metadata={"spec": json.dumps(CONFIG1), "run": json.dumps(run), "weights_sha256": sd_hash(w1),
+                        "n_noise": str(len(draws)), "n_calls": str(len(calls)), "kept_calls": json.dumps(keep)})
+    print("wrote config1_ddpm; weights sha256", sd_hash(w1)[:16])
+
+
+if __name__ == "__main__":
+    main()

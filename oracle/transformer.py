@@ -1,0 +1,129 @@
+"""Oracle: the third-party transformer arithmetic on the path, restated functionally.
+
+The reference's denoiser is ``transformers.BertModel(is_decoder=True, add_cross_attention=True)``
+(/root/reference/src/diffusion/model.py:44-52,193-197) and its context encoder is a HF encoder
+(model.py:31-42,165-170).  transformers is pinned ``~=4.30.2`` in the reference's
+requirements.txt:3 and is NOT under /root/reference; this file restates the published algorithm
+following the installed 5.15.0 sources (``HF:`` = site-packages/transformers):
+
+  bert_embeddings     HF:models/bert/modeling_bert.py:53-108   (inputs_embeds + token_type[0] + pos -> LN)
+  bert_layer          HF:models/bert/modeling_bert.py:139-416  (post-LN; causal self-attn; cross-attn; erf-GELU FFN)
+  bert_decoder        HF:models/bert/modeling_bert.py:594-718  (pooler output is discarded by the caller -> skipped)
+  bert_encoder_model  same file, non-decoder BertModel used as the context encoder for "bert" base names
+  blenderbot_encoder  HF:models/blenderbot/modeling_blenderbot.py:65-300,424-512 (pre-LN, learned pos, final LN)
+
+Masks follow the eager 4.30.2 formulation (additive ``finfo.min``): a fully masked key row gives
+a uniform softmax, never NaN.  All weights are read from a flat state dict with the reference's
+checkpoint key layout.
+TEST INFRASTRUCTURE: see oracle/__init__.py.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _lin(sd, prefix, x):
+    return F.linear(x, sd[prefix + ".weight"], sd.get(prefix + ".bias"))
+
+
+def _ln(sd, prefix, x, eps):
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
+
+
+def _heads(x, n_heads):
+    b, s, h = x.shape
+    return x.view(b, s, n_heads, h // n_heads).transpose(1, 2)
+
+
+def _attend(q, k, v, add_mask):
+    """softmax(q k^T / sqrt(d) + mask) v on [B, A, S, d] tensors -> [B, S, A*d]."""
+    d = q.shape[-1]
+    scores = torch.matmul(q, k.transpose(2, 3)) * (d**-0.5)
+    if add_mask is not None:
+        scores = scores + add_mask
+    p = torch.softmax(scores, dim=-1)
+    o = torch.matmul(p, v).transpose(1, 2)
+    return o.reshape(o.shape[0], o.shape[1], -1)
+
+
+def key_padding_mask(attention_mask, dtype=torch.float32):
+    """[B, C] 0/1 -> additive [B, 1, 1, C]  (HF get_extended_attention_mask / invert_attention_mask)."""
+    m = attention_mask[:, None, None, :].to(dtype)
+    return (1.0 - m) * torch.finfo(dtype).min
+
+
+def causal_mask(s, dtype=torch.float32):
+    """additive [1, 1, S, S]: query i sees keys j <= i (is_decoder=True, HF:bert:696-702)."""
+    allowed = torch.tril(torch.ones(s, s, dtype=torch.bool))
+    m = torch.zeros(s, s, dtype=dtype)
+    m.masked_fill_(~allowed, torch.finfo(dtype).min)
+    return m[None, None]
+
+
+def bert_embeddings(sd, p, inputs_embeds, eps):
+    s = inputs_embeds.shape[1]
+    x = inputs_embeds + sd[p + "token_type_embeddings.weight"][0]
+    x = x + sd[p + "position_embeddings.weight"][:s]
+    return _ln(sd, p + "LayerNorm", x, eps)
+
+
+def bert_layer(sd, p, h, n_heads, eps, self_mask, ctx=None, ctx_mask=None):
+    a = p + "attention."
+    q = _heads(_lin(sd, a + "self.query", h), n_heads)
+    k = _heads(_lin(sd, a + "self.key", h), n_heads)
+    v = _heads(_lin(sd, a + "self.value", h), n_heads)
+    o = _attend(q, k, v, self_mask)
+    h = _ln(sd, a + "output.LayerNorm", _lin(sd, a + "output.dense", o) + h, eps)
+    if ctx is not None:
+        c = p + "crossattention."
+        q = _heads(_lin(sd, c + "self.query", h), n_heads)
+        k = _heads(_lin(sd, c + "self.key", ctx), n_heads)
+        v = _heads(_lin(sd, c + "self.value", ctx), n_heads)
+        o = _attend(q, k, v, ctx_mask)
+        h = _ln(sd, c + "output.LayerNorm", _lin(sd, c + "output.dense", o) + h, eps)
+    inter = F.gelu(_lin(sd, p + "intermediate.dense", h))  # hidden_act="gelu": exact erf form
+    return _ln(sd, p + "output.LayerNorm", _lin(sd, p + "output.dense", inter) + h, eps)
+
+
+def bert_decoder(sd, prefix, inputs_embeds, context, context_attention_mask, n_layers, n_heads, eps=1e-12):
+    """The denoiser body: [B,S,H] noised target (+time embedding already added) -> [B,S,H]."""
+    h = bert_embeddings(sd, prefix + "embeddings.", inputs_embeds, eps)
+    self_mask = causal_mask(h.shape[1], h.dtype)
+    ctx_mask = key_padding_mask(context_attention_mask, h.dtype) if context_attention_mask is not None else None
+    for i in range(n_layers):
+        h = bert_layer(sd, f"{prefix}encoder.layer.{i}.", h, n_heads, eps, self_mask, context, ctx_mask)
+    return h
+
+
+def bert_encoder_model(sd, prefix, input_ids, attention_mask, n_layers, n_heads, eps=1e-12):
+    """Non-causal BertModel as context encoder ("bert" base names, model.py:31-35)."""
+    p = prefix + "embeddings."
+    x = F.embedding(input_ids, sd[p + "word_embeddings.weight"])
+    h = bert_embeddings(sd, p, x, eps)
+    mask = key_padding_mask(attention_mask, h.dtype)
+    for i in range(n_layers):
+        h = bert_layer(sd, f"{prefix}encoder.layer.{i}.", h, n_heads, eps, mask)
+    return h
+
+
+def blenderbot_encoder(sd, prefix, input_ids, attention_mask, n_layers, n_heads, scale_embedding=True, eps=1e-5):
+    """Pre-LN encoder with learned positions and a final LayerNorm (HF:blenderbot:424-512)."""
+    d = sd[prefix + "embed_tokens.weight"].shape[1]
+    x = F.embedding(input_ids, sd[prefix + "embed_tokens.weight"])
+    if scale_embedding:
+        x = x * math.sqrt(d)
+    h = x + sd[prefix + "embed_positions.weight"][: input_ids.shape[1]]
+    mask = key_padding_mask(attention_mask, h.dtype)
+    for i in range(n_layers):
+        p = f"{prefix}layers.{i}."
+        r = h
+        y = _ln(sd, p + "self_attn_layer_norm", h, eps)
+        q = _heads(_lin(sd, p + "self_attn.q_proj", y), n_heads)
+        k = _heads(_lin(sd, p + "self_attn.k_proj", y), n_heads)
+        v = _heads(_lin(sd, p + "self_attn.v_proj", y), n_heads)
+        h = r + _lin(sd, p + "self_attn.out_proj", _attend(q, k, v, mask))
+        r = h
+        y = _ln(sd, p + "final_layer_norm", h, eps)
+        h = r + _lin(sd, p + "fc2", F.gelu(_lin(sd, p + "fc1", y)))
+    return _ln(sd, prefix + "layer_norm", h, eps)

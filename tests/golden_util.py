@@ -1,0 +1,97 @@
+"""Shared helpers for the golden fixtures (used by oracle/make_golden.py and the tests)."""
+import hashlib
+import json
+import os
+
+import torch
+from safetensors import safe_open
+
+from didi_amd.config import DiDiConfig, tiny_config1
+from didi_amd.synthetic import synthetic_batch, synthetic_state_dict
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def config1() -> DiDiConfig:
+    return tiny_config1()
+
+
+def config1_state_dict():
+    return synthetic_state_dict(config1(), seed=1234)
+
+
+def config1_inputs():
+    return synthetic_batch(8, 24, 8008, seed=7)
+
+
+def sd_hash(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def load_case(name):
+    """-> (tensors dict, metadata dict with json fields decoded)."""
+    path = os.path.join(GOLDEN, name + ".safetensors")
+    with safe_open(path, framework="pt") as f:
+        t = {k: f.get_tensor(k) for k in f.keys()}
+        meta = dict(f.metadata() or {})
+    for k in ("spec", "run", "kept_calls"):
+        if k in meta:
+            meta[k] = json.loads(meta[k])
+    return t, meta
+
+
+def weights_of(tensors):
+    return {k[2:]: v for k, v in tensors.items() if k.startswith("w.")}
+
+
+def spec_to_config(spec) -> DiDiConfig:
+    return DiDiConfig(
+        vocab=spec["vocab"], dec_dim=spec["dec_dim"], dec_layers=spec["dec_layers"], dec_heads=spec["dec_heads"],
+        dec_ffn=spec["dec_ffn"], enc_kind=spec["enc_kind"], enc_dim=spec["enc_dim"], enc_layers=spec["enc_layers"],
+        enc_heads=spec["enc_heads"], enc_ffn=spec["enc_ffn"], diffusion_steps=spec["T"], schedule=spec["schedule"],
+        s_churn=spec.get("s_churn", 0.0), s_tmin=spec.get("s_tmin", 0.0), s_tmax=spec.get("s_tmax", float("inf")),
+        enc_ln_eps=1e-12 if spec["enc_kind"] == "bert" else 1e-5,
+    )
+
+
+def spec_to_oracle_config(spec):
+    from oracle.model import OracleConfig
+
+    return OracleConfig(
+        vocab=spec["vocab"], dec_dim=spec["dec_dim"], dec_layers=spec["dec_layers"], dec_heads=spec["dec_heads"],
+        enc_kind=spec["enc_kind"], enc_dim=spec["enc_dim"], enc_layers=spec["enc_layers"], enc_heads=spec["enc_heads"],
+        diffusion_steps=spec["T"], schedule=spec["schedule"], s_churn=spec.get("s_churn", 0.0),
+        s_tmin=spec.get("s_tmin", 0.0), s_tmax=spec.get("s_tmax", float("inf")),
+    )
+
+
+def config_to_oracle_config(cfg: DiDiConfig):
+    from oracle.model import OracleConfig
+
+    return OracleConfig(
+        vocab=cfg.vocab, dec_dim=cfg.dec_dim, dec_layers=cfg.dec_layers, dec_heads=cfg.dec_heads,
+        enc_kind=cfg.enc_kind, enc_dim=cfg.enc_dim, enc_layers=cfg.enc_layers, enc_heads=cfg.enc_heads,
+        enc_scale_embedding=cfg.enc_scale_embedding, diffusion_steps=cfg.diffusion_steps, schedule=cfg.schedule,
+        s_churn=cfg.s_churn, s_tmin=cfg.s_tmin, s_tmax=cfg.s_tmax, dec_ln_eps=cfg.dec_ln_eps, enc_ln_eps=cfg.enc_ln_eps,
+    )
+
+
+class ListNoise:
+    """noise_source that replays a captured stream."""
+
+    def __init__(self, draws):
+        self.draws, self.i = list(draws), 0
+
+    def __call__(self, shape):
+        d = self.draws[self.i]
+        self.i += 1
+        assert tuple(d.shape) == tuple(shape), (d.shape, shape)
+        return d.clone()
+
+
+def noise_list(tensors, n):
+    return [tensors[f"noise.{i}"] for i in range(n)]

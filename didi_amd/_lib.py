@@ -1,0 +1,163 @@
+"""ctypes binding of libdidi_hip.so (the C ABI in include/didi_hip.h).
+
+The structures below mirror the header field-for-field (same order, same types).  The library is
+built in-tree by ``__graft_entry__.build()`` / ``make -C didi_amd/csrc``; if it is missing or
+fails to load, importing this module raises: there is no fallback path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdidi_hip.so")
+
+u16p = C.POINTER(C.c_uint16)
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+
+OK = 0
+PREC_BF16, PREC_BF16X3 = 1, 3
+ACT_NONE, ACT_GELU, ACT_TANH = 0, 1, 2
+STEP_NONE, STEP_INIT, STEP_DDPM, STEP_EULER = 0, 1, 2, 3
+
+
+class StepArgs(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int), ("M", C.c_int), ("S", C.c_int), ("H", C.c_int),
+        ("X", C.c_void_p), ("X0", C.c_void_p), ("E", C.c_void_p),
+        ("cx0", C.c_float), ("ce", C.c_float), ("ratio", C.c_float), ("cin", C.c_float),
+        ("seed", C.c_uint64), ("offset", C.c_uint64),
+        ("x_out", C.c_void_p), ("xin_out", C.c_void_p),
+        ("time_embeds", C.c_void_p), ("t", C.c_int), ("time_idx", C.c_void_p),
+        ("pos_emb", C.c_void_p), ("tok_type0", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
+        ("ln_eps", C.c_float), ("h_hi", C.c_void_p), ("h_lo", C.c_void_p),
+    ]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("precision", C.c_int),
+        ("A_hi", C.c_void_p), ("A_lo", C.c_void_p), ("lda", C.c_int),
+        ("W_hi", C.c_void_p), ("W_lo", C.c_void_p), ("ldw", C.c_int),
+        ("bias", C.c_void_p), ("act", C.c_int),
+        ("R_f32", C.c_void_p), ("R_hi", C.c_void_p), ("R_lo", C.c_void_p), ("ldr", C.c_int),
+        ("C_f32", C.c_void_p), ("C_hi", C.c_void_p), ("C_lo", C.c_void_p), ("ldc", C.c_int),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("heads", C.c_int), ("Sq", C.c_int), ("Sk", C.c_int), ("D", C.c_int),
+        ("precision", C.c_int), ("causal", C.c_int), ("key_mask", C.c_void_p),
+        ("Q_hi", C.c_void_p), ("Q_lo", C.c_void_p), ("ldq", C.c_int),
+        ("K_hi", C.c_void_p), ("K_lo", C.c_void_p), ("ldk", C.c_int),
+        ("V_hi", C.c_void_p), ("V_lo", C.c_void_p), ("ldv", C.c_int),
+        ("O_hi", C.c_void_p), ("O_lo", C.c_void_p), ("ldo", C.c_int),
+    ]
+
+
+class Linear(C.Structure):
+    _fields_ = [("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("bias", C.c_void_p), ("N", C.c_int), ("K", C.c_int)]
+
+
+class DecoderLayer(C.Structure):
+    _fields_ = [
+        ("qkv", Linear), ("attn_out", Linear), ("ln1_g", C.c_void_p), ("ln1_b", C.c_void_p),
+        ("cq", Linear), ("ckv", Linear), ("cross_out", Linear), ("ln2_g", C.c_void_p), ("ln2_b", C.c_void_p),
+        ("ffn_up", Linear), ("ffn_down", Linear), ("ln3_g", C.c_void_p), ("ln3_b", C.c_void_p),
+    ]
+
+
+class Decoder(C.Structure):
+    _fields_ = [
+        ("H", C.c_int), ("heads", C.c_int), ("I", C.c_int), ("L", C.c_int), ("ln_eps", C.c_float),
+        ("time_embeds", C.c_void_p), ("pos_emb", C.c_void_p), ("tok_type0", C.c_void_p),
+        ("emb_ln_g", C.c_void_p), ("emb_ln_b", C.c_void_p), ("layers_host", C.POINTER(DecoderLayer)),
+    ]
+
+
+class ForwardArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("S", C.c_int), ("C", C.c_int), ("precision", C.c_int),
+        ("step", StepArgs),
+        ("kv_hi", C.c_void_p), ("kv_lo", C.c_void_p), ("ctx_mask", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("x0_f32", C.c_void_p), ("x0_hi", C.c_void_p), ("x0_lo", C.c_void_p),
+    ]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("S", C.c_int), ("C", C.c_int), ("precision", C.c_int), ("euler", C.c_int), ("n_calls", C.c_int),
+        ("time_row_host", i32p), ("c0_host", f32p), ("c1_host", f32p), ("c2_host", f32p),
+        ("init_scale", C.c_float), ("noise", C.c_void_p), ("seed", C.c_uint64), ("base_offset", C.c_uint64),
+        ("xt_trace", C.c_void_p), ("kv_hi", C.c_void_p), ("kv_lo", C.c_void_p), ("ctx_mask", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("x_state", C.c_void_p), ("x0_f32", C.c_void_p), ("x0_hi", C.c_void_p), ("x0_lo", C.c_void_p),
+        ("cls_hi", C.c_void_p), ("cls_lo", C.c_void_p), ("V", C.c_int), ("argmax_partial", C.c_void_p),
+        ("ids64", C.c_void_p),
+    ]
+
+
+# every symbol include/didi_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("didi_version", C.c_int, []),
+    ("didi_error_string", C.c_char_p, [C.c_int]),
+    ("didi_split_bf16", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("didi_philox_normal", C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]),
+    ("didi_step_embed_ln", C.c_int, [C.POINTER(StepArgs), C.c_void_p]),
+    ("didi_embed_gather", C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p]),
+    ("didi_layernorm", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("didi_gemm_bf16", C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    ("didi_round_argmax_bytes", C.c_size_t, [C.c_int, C.c_int]),
+    ("didi_round_argmax", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("didi_first_eos", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("didi_attention", C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
+    ("didi_decoder_workspace_bytes", C.c_size_t, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int]),
+    ("didi_decoder_kv_plane_bytes", C.c_size_t, [C.POINTER(Decoder), C.c_int, C.c_int]),
+    ("didi_decoder_prepare_context", C.c_int, [C.POINTER(Decoder), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                               C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("didi_decoder_forward", C.c_int, [C.POINTER(Decoder), C.POINTER(ForwardArgs), C.c_void_p]),
+    ("didi_sample", C.c_int, [C.POINTER(Decoder), C.POINTER(SampleArgs), C.c_void_p]),
+]
+
+
+class DidiHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C didi_amd/csrc`.  didi_amd has no non-HIP fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if lib.didi_version() != 1:
+        raise ImportError(f"libdidi_hip ABI version {lib.didi_version()} != 1")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != OK:
+        raise DidiHipError(f"{what}: {lib.didi_error_string(rc).decode()} ({rc})")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, or None."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

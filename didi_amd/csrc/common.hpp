@@ -1,0 +1,57 @@
+// Shared device/host helpers for libdidi_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/didi_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short u16;
+
+#define DIDI_CHECK_ARG(cond)                 \
+    do {                                     \
+        if (!(cond)) return DIDI_ERR_BAD_ARG; \
+    } while (0)
+
+#define DIDI_LAUNCH_CHECK()                                      \
+    do {                                                         \
+        if (hipGetLastError() != hipSuccess) return DIDI_ERR_LAUNCH; \
+    } while (0)
+
+// ---- split-bf16 representation -------------------------------------------------------------
+// An fp32 value x travels as two bf16 planes: hi = bf16(x) (round-to-nearest-even) and
+// lo = bf16(x - hi).  hi + lo carries ~16 mantissa bits.  "bf16" GEMM mode multiplies hi planes
+// only; "bf16x3" mode adds the hi*lo and lo*hi cross terms into the same fp32 accumulator.
+__device__ __forceinline__ u16 bf16_bits(float x) { return __builtin_bit_cast(u16, (__bf16)x); }
+__device__ __forceinline__ float bf16_to_f32(u16 b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+
+__device__ __forceinline__ void split2(float x, u16& hi, u16& lo) {
+    hi = bf16_bits(x);
+    lo = bf16_bits(x - bf16_to_f32(hi));
+}
+__device__ __forceinline__ float join2(u16 hi, u16 lo) { return bf16_to_f32(hi) + bf16_to_f32(lo); }
+
+// 4 consecutive values -> two 8-byte packs (hi plane, lo plane)
+__device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo) {
+    u16 h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2(v[i], h[i], l[i]);
+    hi = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+}
+__device__ __forceinline__ void unpack4(uint2 p, float v[4]) {
+    v[0] = bf16_to_f32((u16)(p.x & 0xffff));
+    v[1] = bf16_to_f32((u16)(p.x >> 16));
+    v[2] = bf16_to_f32((u16)(p.y & 0xffff));
+    v[3] = bf16_to_f32((u16)(p.y >> 16));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

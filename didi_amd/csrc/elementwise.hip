@@ -1,0 +1,314 @@
+// Row / elementwise kernels of the sampler path: HBM-bound, one pass over the [M, H] state each.
+//
+// Layout: one 64-lane wave owns one row of H fp32 values, lane l holding the 16-byte chunks
+// c = l + 64*j (so a wave-instruction reads 1 KiB contiguous); four rows per 256-thread block.
+// LayerNorm statistics are two-pass in registers (mean, then sum of squared deviations) with a
+// wave butterfly -- no LDS, no second trip to memory.  Algorithmic bytes per row are listed at
+// each kernel; DESIGN.md section "Kernels" carries the roofline arithmetic.
+#include "common.hpp"
+
+// ------------------------------------------------------------------ Philox4x32-10 + Box-Muller
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t key, uint32_t out[4]) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void philox_normal4(uint64_t ctr, uint64_t seed, float z[4]) {
+    uint32_t r[4];
+    philox4x32_10(ctr, seed, r);
+    const float k = 2.3283064365386963e-10f;  // 2^-32
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u1 = ((float)r[2 * p] + 0.5f) * k;  // (0, 1]
+        const float u2 = ((float)r[2 * p + 1] + 0.5f) * k;
+        const float rad = sqrtf(-2.0f * logf(u1));
+        float s, c;
+        sincosf(6.283185307179586f * u2, &s, &c);
+        z[2 * p] = rad * c;
+        z[2 * p + 1] = rad * s;
+    }
+}
+
+__global__ void __launch_bounds__(256) philox_normal_kernel(float* out, size_t n4, uint64_t seed, uint64_t offset) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float z[4];
+        philox_normal4(offset + i, seed, z);
+        reinterpret_cast<float4*>(out)[i] = make_float4(z[0], z[1], z[2], z[3]);
+    }
+}
+
+extern "C" int didi_philox_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+    DIDI_CHECK_ARG(out && n % 4 == 0);
+    if (n == 0) return DIDI_OK;
+    const size_t n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    philox_normal_kernel<<<grid, 256, 0, as_stream(stream)>>>(out, n4, seed, offset);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ fp32 -> split planes
+// bytes per element: 4 read + 4 written.
+__global__ void __launch_bounds__(256) split_kernel(const float* src, u16* hi, u16* lo, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        uint2 h, l;
+        split4(f, h, l);
+        reinterpret_cast<uint2*>(hi)[i] = h;
+        if (lo) reinterpret_cast<uint2*>(lo)[i] = l;
+    }
+}
+
+extern "C" int didi_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, size_t n, void* stream) {
+    DIDI_CHECK_ARG(src && hi && n % 4 == 0);
+    if (n == 0) return DIDI_OK;
+    const size_t n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    split_kernel<<<grid, 256, 0, as_stream(stream)>>>(src, hi, lo, n4);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ LayerNorm tail shared by both row kernels
+template <int MAXV>
+__device__ __forceinline__ void ln_row_store(float (&v)[MAXV][4], int lane, int H, size_t row_off, const float* gamma,
+                                             const float* beta, float eps, u16* y_hi, u16* y_lo, float* y_f32) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c * 4 < H) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c * 4 < H) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[j][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c * 4 < H) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+            const float4 b = reinterpret_cast<const float4*>(beta)[c];
+            float y[4];
+            y[0] = (v[j][0] - mean) * rstd * g.x + b.x;
+            y[1] = (v[j][1] - mean) * rstd * g.y + b.y;
+            y[2] = (v[j][2] - mean) * rstd * g.z + b.z;
+            y[3] = (v[j][3] - mean) * rstd * g.w + b.w;
+            const size_t o = row_off + (size_t)c * 4;
+            if (y_f32) *reinterpret_cast<float4*>(y_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
+            if (y_hi) {
+                uint2 h, l;
+                split4(y, h, l);
+                *reinterpret_cast<uint2*>(y_hi + o) = h;
+                if (y_lo) *reinterpret_cast<uint2*>(y_lo + o) = l;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm
+// bytes per row: 4H read + (2H | 4H) planes [+ 4H fp32] written.
+template <int MAXV>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* x, const float* gamma, const float* beta, float eps,
+                                                        int M, int H, u16* y_hi, u16* y_lo, float* y_f32) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const size_t row_off = (size_t)m * H;
+    float v[MAXV][4];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c * 4 < H) {
+            const float4 t = reinterpret_cast<const float4*>(x + row_off)[c];
+            v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
+        } else {
+            v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+        }
+    }
+    ln_row_store<MAXV>(v, lane, H, row_off, gamma, beta, eps, y_hi, y_lo, y_f32);
+}
+
+extern "C" int didi_layernorm(const float* x, const float* gamma, const float* beta, float eps, int M, int H,
+                              uint16_t* y_hi, uint16_t* y_lo, float* y_f32, void* stream) {
+    DIDI_CHECK_ARG(x && gamma && beta && (y_hi || y_f32) && M >= 0 && H > 0);
+    DIDI_CHECK_ARG(!(y_lo && !y_hi));
+    if (H % 4 != 0 || H > 2048) return DIDI_ERR_UNSUPPORTED;
+    if (M == 0) return DIDI_OK;
+    const int grid = cdiv(M, 4);
+    hipStream_t st = as_stream(stream);
+    if (H <= 256) layernorm_kernel<1><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32);
+    else if (H <= 768) layernorm_kernel<3><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32);
+    else if (H <= 1280) layernorm_kernel<5><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32);
+    else layernorm_kernel<8><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ sampler step + decoder prologue
+// bytes per row (H fp32 = 4H): DDPM reads x0 (4H) [+ eps 4H when injected], writes planes (4H)
+// [+ x_t 4H when traced]; the reference makes 3 elementwise passes + gather + add + LN passes.
+template <int MAXV>
+__global__ void __launch_bounds__(256) step_embed_ln_kernel(didi_step_args a) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const int H = a.H;
+    const size_t row_off = (size_t)m * H;
+    const int s = m % a.S;
+    const int t = a.time_idx ? a.time_idx[m / a.S] : a.t;
+    const bool draw = (a.E == nullptr) && (a.ce != 0.f) && (a.mode != DIDI_STEP_NONE);
+    float v[MAXV][4];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c * 4 < H) {
+            float x[4] = {0.f, 0.f, 0.f, 0.f}, x0[4] = {0.f, 0.f, 0.f, 0.f}, e[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.mode == DIDI_STEP_EULER || a.mode == DIDI_STEP_NONE) {
+                const float4 q = reinterpret_cast<const float4*>(a.X + row_off)[c];
+                x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+            }
+            if (a.mode == DIDI_STEP_DDPM || a.mode == DIDI_STEP_EULER) {
+                const float4 q = reinterpret_cast<const float4*>(a.X0 + row_off)[c];
+                x0[0] = q.x; x0[1] = q.y; x0[2] = q.z; x0[3] = q.w;
+            }
+            if (a.E && a.mode != DIDI_STEP_NONE) {
+                const float4 q = reinterpret_cast<const float4*>(a.E + row_off)[c];
+                e[0] = q.x; e[1] = q.y; e[2] = q.z; e[3] = q.w;
+            } else if (draw) {
+                philox_normal4(a.offset + (row_off / 4 + c), a.seed, e);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float r;
+                if (a.mode == DIDI_STEP_INIT) r = a.ce * e[k];
+                else if (a.mode == DIDI_STEP_DDPM) r = a.cx0 * x0[k] + a.ce * e[k];
+                else if (a.mode == DIDI_STEP_EULER) r = (x[k] + (x[k] - x0[k]) * a.ratio) + a.ce * e[k];
+                else r = x[k];
+                x[k] = r;
+            }
+            if (a.x_out) *reinterpret_cast<float4*>(a.x_out + row_off + (size_t)c * 4) = make_float4(x[0], x[1], x[2], x[3]);
+            if (a.xin_out)
+                *reinterpret_cast<float4*>(a.xin_out + row_off + (size_t)c * 4) =
+                    make_float4(a.cin * x[0], a.cin * x[1], a.cin * x[2], a.cin * x[3]);
+            if (a.h_hi) {
+                const float4 te = reinterpret_cast<const float4*>(a.time_embeds + (size_t)t * H)[c];
+                const float4 tk = reinterpret_cast<const float4*>(a.tok_type0)[c];
+                const float4 ps = reinterpret_cast<const float4*>(a.pos_emb + (size_t)s * H)[c];
+                // (x + time) + token_type + position: the reference's association order
+                v[j][0] = ((a.cin * x[0] + te.x) + tk.x) + ps.x;
+                v[j][1] = ((a.cin * x[1] + te.y) + tk.y) + ps.y;
+                v[j][2] = ((a.cin * x[2] + te.z) + tk.z) + ps.z;
+                v[j][3] = ((a.cin * x[3] + te.w) + tk.w) + ps.w;
+            }
+        } else {
+            v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+        }
+    }
+    if (a.h_hi) ln_row_store<MAXV>(v, lane, H, row_off, a.ln_gamma, a.ln_beta, a.ln_eps, a.h_hi, a.h_lo, nullptr);
+}
+
+extern "C" int didi_step_embed_ln(const didi_step_args* a, void* stream) {
+    DIDI_CHECK_ARG(a && a->M >= 0 && a->S > 0 && a->H > 0 && a->M % a->S == 0);
+    DIDI_CHECK_ARG(a->mode >= DIDI_STEP_NONE && a->mode <= DIDI_STEP_EULER);
+    if (a->mode == DIDI_STEP_EULER || a->mode == DIDI_STEP_NONE) DIDI_CHECK_ARG(a->X);
+    if (a->mode == DIDI_STEP_DDPM || a->mode == DIDI_STEP_EULER) DIDI_CHECK_ARG(a->X0);
+    DIDI_CHECK_ARG(a->h_hi || a->x_out || a->xin_out);
+    if (a->h_hi) DIDI_CHECK_ARG(a->h_lo && a->time_embeds && a->pos_emb && a->tok_type0 && a->ln_gamma && a->ln_beta);
+    if (a->H % 4 != 0 || a->H > 2048) return DIDI_ERR_UNSUPPORTED;
+    if (a->M == 0) return DIDI_OK;
+    const int grid = cdiv(a->M, 4);
+    hipStream_t st = as_stream(stream);
+    if (a->H <= 256) step_embed_ln_kernel<1><<<grid, 256, 0, st>>>(*a);
+    else if (a->H <= 768) step_embed_ln_kernel<3><<<grid, 256, 0, st>>>(*a);
+    else if (a->H <= 1280) step_embed_ln_kernel<5><<<grid, 256, 0, st>>>(*a);
+    else step_embed_ln_kernel<8><<<grid, 256, 0, st>>>(*a);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ token-embedding gather (encoder input)
+__global__ void __launch_bounds__(256) embed_gather_kernel(const int64_t* ids, const float* table, float scale,
+                                                           const float* pos, int M, int S, int H, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* src = table + (size_t)ids[m] * H;
+    const float* ps = pos ? pos + (size_t)(m % S) * H : nullptr;
+    for (int c = lane; c * 4 < H; c += 64) {
+        float4 v = reinterpret_cast<const float4*>(src)[c];
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        if (ps) {
+            const float4 q = reinterpret_cast<const float4*>(ps)[c];
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        reinterpret_cast<float4*>(out + (size_t)m * H)[c] = v;
+    }
+}
+
+extern "C" int didi_embed_gather(const int64_t* ids, const float* table, float scale, const float* pos, int M, int S, int H,
+                                 float* out, void* stream) {
+    DIDI_CHECK_ARG(ids && table && out && M >= 0 && S > 0 && H > 0 && H % 4 == 0);
+    if (M == 0) return DIDI_OK;
+    embed_gather_kernel<<<cdiv(M, 4), 256, 0, as_stream(stream)>>>(ids, table, scale, pos, M, S, H, out);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ eos truncation lengths
+__global__ void __launch_bounds__(256) first_eos_kernel(const int64_t* ids, int B, int S, int64_t eos, int32_t* lengths) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    int len = S;
+    for (int s = 0; s < S; ++s) {
+        if (ids[(size_t)b * S + s] == eos) { len = s + 1; break; }
+    }
+    lengths[b] = len;
+}
+
+extern "C" int didi_first_eos(const int64_t* ids, int B, int S, int64_t eos_id, int32_t* lengths, void* stream) {
+    DIDI_CHECK_ARG(ids && lengths && B >= 0 && S >= 0);
+    if (B == 0) return DIDI_OK;
+    first_eos_kernel<<<cdiv(B, 256), 256, 0, as_stream(stream)>>>(ids, B, S, eos_id, lengths);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ misc
+extern "C" int didi_version(void) { return DIDI_ABI_VERSION; }
+
+extern "C" const char* didi_error_string(int code) {
+    switch (code) {
+        case DIDI_OK: return "ok";
+        case DIDI_ERR_BAD_ARG: return "bad argument (null pointer, size or alignment constraint)";
+        case DIDI_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
+        case DIDI_ERR_LAUNCH: return "kernel launch failed";
+        case DIDI_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown error";
+    }
+}

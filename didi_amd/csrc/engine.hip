@@ -1,0 +1,244 @@
+// Host-side engine: enqueues the kernels of one denoiser call / one whole sampling loop on a HIP
+// stream.  No allocation, no synchronisation, no host<->device copies: every per-step scalar
+// (time-embedding row, a_t, b_t, churn, ...) is data-independent and comes from the host-side
+// plan (didi_amd/schedule.py) as kernel arguments, so the loop never waits on the device.
+//
+// Workspace layout for M = B*S target rows (all offsets 256-byte aligned):
+//   h   planes [2][M][H]   bf16   residual stream (always hi+lo: the residual add reads both)
+//   qkv planes [2][M][3H]  bf16   self-attention projections; its first [M][H] doubles as the
+//                                 cross-attention query buffer once self-attention is done
+//   att planes [2][M][H]   bf16   attention output (concatenated heads)
+//   ffn planes [2][M][I]   bf16   GELU(FFN-up)
+//   tmp        [M][H]      fp32   pre-LayerNorm sum (dense + bias + residual)
+// didi_decoder_prepare_context uses the front of the same buffer for the context planes.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace {
+
+struct Carve {
+    u16 *h_hi, *h_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *ffn_hi, *ffn_lo;
+    float* tmp;
+    size_t total;
+};
+
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+Carve carve(const didi_decoder* d, int B, int S, char* base) {
+    const size_t M = (size_t)B * S, H = d->H, I = d->I;
+    Carve c{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += al256(bytes); return p; };
+    c.h_hi = (u16*)take(M * H * 2);
+    c.h_lo = (u16*)take(M * H * 2);
+    c.qkv_hi = (u16*)take(M * 3 * H * 2);
+    c.qkv_lo = (u16*)take(M * 3 * H * 2);
+    c.att_hi = (u16*)take(M * H * 2);
+    c.att_lo = (u16*)take(M * H * 2);
+    c.ffn_hi = (u16*)take(M * I * 2);
+    c.ffn_lo = (u16*)take(M * I * 2);
+    c.tmp = (float*)take(M * H * 4);
+    c.total = o;
+    return c;
+}
+
+bool shapes_ok(const didi_decoder* d, int B, int S, int C) {
+    if (!d || B <= 0 || S <= 0 || C <= 0 || d->L <= 0 || d->heads <= 0) return false;
+    if (d->H % d->heads != 0) return false;
+    const int D = d->H / d->heads;
+    if (D % 8 != 0 || D > 64) return false;
+    if (S > 96 || C > 96) return false;
+    if (d->H % 8 != 0 || d->I % 8 != 0 || d->H > 2048) return false;
+    return true;
+}
+
+int gemm(const didi_linear& w, int precision, int M, const u16* a_hi, const u16* a_lo, int lda, int act, const u16* r_hi,
+         const u16* r_lo, int ldr, float* c_f32, u16* c_hi, u16* c_lo, int ldc, void* stream) {
+    didi_gemm_args g{};
+    g.M = M; g.N = w.N; g.K = w.K; g.precision = precision;
+    g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
+    g.W_hi = w.w_hi; g.W_lo = w.w_lo; g.ldw = w.K;
+    g.bias = w.bias; g.act = act;
+    g.R_hi = r_hi; g.R_lo = r_lo; g.ldr = ldr;
+    g.C_f32 = c_f32; g.C_hi = c_hi; g.C_lo = c_lo; g.ldc = ldc;
+    return didi_gemm_bf16(&g, stream);
+}
+
+}  // namespace
+
+#define TRY(x)                     \
+    do {                           \
+        int rc_ = (x);             \
+        if (rc_ != DIDI_OK) return rc_; \
+    } while (0)
+
+extern "C" size_t didi_decoder_workspace_bytes(const didi_decoder* dec, int B, int S, int C) {
+    if (!shapes_ok(dec, B, S, C)) return 0;
+    const size_t fwd = carve(dec, B, S, nullptr).total;
+    const size_t ctx = 2 * al256((size_t)B * C * dec->H * 2);
+    return std::max(fwd, ctx);
+}
+
+extern "C" size_t didi_decoder_kv_plane_bytes(const didi_decoder* dec, int B, int C) {
+    if (!dec || B <= 0 || C <= 0) return 0;
+    return (size_t)dec->L * B * C * 2 * dec->H * sizeof(u16);
+}
+
+extern "C" int didi_decoder_prepare_context(const didi_decoder* dec, const float* ctx, int B, int C, int precision,
+                                            void* workspace, size_t workspace_bytes, uint16_t* kv_hi, uint16_t* kv_lo,
+                                            void* stream) {
+    DIDI_CHECK_ARG(dec && ctx && workspace && kv_hi && dec->layers_host);
+    DIDI_CHECK_ARG(precision == DIDI_PREC_BF16 || (precision == DIDI_PREC_BF16X3 && kv_lo));
+    if (!shapes_ok(dec, B, 1, C)) return DIDI_ERR_UNSUPPORTED;
+    const size_t Mc = (size_t)B * C, H = dec->H;
+    const size_t plane = al256(Mc * H * 2);
+    if (workspace_bytes < 2 * plane) return DIDI_ERR_WORKSPACE;
+    u16* c_hi = (u16*)workspace;
+    u16* c_lo = (u16*)((char*)workspace + plane);
+    TRY(didi_split_bf16(ctx, c_hi, c_lo, Mc * H, stream));
+    for (int l = 0; l < dec->L; ++l) {
+        const didi_decoder_layer& ly = dec->layers_host[l];
+        DIDI_CHECK_ARG(ly.ckv.N == 2 * dec->H && ly.ckv.K == dec->H);
+        const size_t off = (size_t)l * Mc * 2 * H;
+        TRY(gemm(ly.ckv, precision, (int)Mc, c_hi, c_lo, (int)H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, kv_hi + off,
+                 precision == DIDI_PREC_BF16X3 ? kv_lo + off : nullptr, (int)(2 * H), stream));
+    }
+    return DIDI_OK;
+}
+
+extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_args* a, void* stream) {
+    DIDI_CHECK_ARG(dec && a && dec->layers_host && a->workspace && a->x0_f32 && a->kv_hi && a->ctx_mask);
+    const int prec = a->precision;
+    DIDI_CHECK_ARG(prec == DIDI_PREC_BF16 || (prec == DIDI_PREC_BF16X3 && a->kv_lo));
+    DIDI_CHECK_ARG(!(a->x0_lo && !a->x0_hi));
+    if (!shapes_ok(dec, a->B, a->S, a->C)) return DIDI_ERR_UNSUPPORTED;
+    if (a->S > 0 && dec->pos_emb == nullptr) return DIDI_ERR_BAD_ARG;
+    const Carve w = carve(dec, a->B, a->S, (char*)a->workspace);
+    if (a->workspace_bytes < w.total) return DIDI_ERR_WORKSPACE;
+    const int M = a->B * a->S, H = dec->H, I = dec->I, D = H / dec->heads;
+    const bool x3 = prec == DIDI_PREC_BF16X3;
+    const size_t Mc = (size_t)a->B * a->C;
+
+    // sampler step + time embedding + BertEmbeddings
+    didi_step_args st = a->step;
+    st.M = M; st.S = a->S; st.H = H;
+    st.time_embeds = dec->time_embeds; st.pos_emb = dec->pos_emb; st.tok_type0 = dec->tok_type0;
+    st.ln_gamma = dec->emb_ln_g; st.ln_beta = dec->emb_ln_b; st.ln_eps = dec->ln_eps;
+    st.h_hi = w.h_hi; st.h_lo = w.h_lo;
+    TRY(didi_step_embed_ln(&st, stream));
+
+    for (int l = 0; l < dec->L; ++l) {
+        const didi_decoder_layer& ly = dec->layers_host[l];
+        const bool last = l == dec->L - 1;
+        // --- causal self-attention block
+        TRY(gemm(ly.qkv, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, w.qkv_hi,
+                 x3 ? w.qkv_lo : nullptr, 3 * H, stream));
+        didi_attn_args at{};
+        at.B = a->B; at.heads = dec->heads; at.Sq = a->S; at.Sk = a->S; at.D = D; at.precision = prec;
+        at.causal = 1; at.key_mask = nullptr;
+        at.Q_hi = w.qkv_hi; at.Q_lo = x3 ? w.qkv_lo : nullptr; at.ldq = 3 * H;
+        at.K_hi = w.qkv_hi + H; at.K_lo = x3 ? w.qkv_lo + H : nullptr; at.ldk = 3 * H;
+        at.V_hi = w.qkv_hi + 2 * H; at.V_lo = x3 ? w.qkv_lo + 2 * H : nullptr; at.ldv = 3 * H;
+        at.O_hi = w.att_hi; at.O_lo = x3 ? w.att_lo : nullptr; at.ldo = H;
+        TRY(didi_attention(&at, stream));
+        TRY(gemm(ly.attn_out, prec, M, w.att_hi, w.att_lo, H, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream));
+        TRY(didi_layernorm(w.tmp, ly.ln1_g, ly.ln1_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, stream));
+        // --- cross-attention block (K/V hoisted: didi_decoder_prepare_context)
+        u16* q_hi = w.qkv_hi;
+        u16* q_lo = x3 ? w.qkv_lo : nullptr;
+        TRY(gemm(ly.cq, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream));
+        const size_t kvoff = (size_t)l * Mc * 2 * H;
+        at.Sk = a->C; at.causal = 0; at.key_mask = a->ctx_mask;
+        at.Q_hi = q_hi; at.Q_lo = q_lo; at.ldq = H;
+        at.K_hi = a->kv_hi + kvoff; at.K_lo = x3 ? a->kv_lo + kvoff : nullptr; at.ldk = 2 * H;
+        at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;
+        TRY(didi_attention(&at, stream));
+        TRY(gemm(ly.cross_out, prec, M, w.att_hi, w.att_lo, H, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream));
+        TRY(didi_layernorm(w.tmp, ly.ln2_g, ly.ln2_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, stream));
+        // --- feed-forward block
+        TRY(gemm(ly.ffn_up, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_GELU, nullptr, nullptr, 0, nullptr, w.ffn_hi,
+                 x3 ? w.ffn_lo : nullptr, I, stream));
+        TRY(gemm(ly.ffn_down, prec, M, w.ffn_hi, w.ffn_lo, I, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream));
+        if (!last) {
+            TRY(didi_layernorm(w.tmp, ly.ln3_g, ly.ln3_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, stream));
+        } else {
+            u16* o_hi = a->x0_hi ? a->x0_hi : w.h_hi;
+            u16* o_lo = a->x0_hi ? a->x0_lo : w.h_lo;
+            TRY(didi_layernorm(w.tmp, ly.ln3_g, ly.ln3_b, dec->ln_eps, M, H, o_hi, o_lo, a->x0_f32, stream));
+        }
+    }
+    return DIDI_OK;
+}
+
+extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, void* stream) {
+    DIDI_CHECK_ARG(dec && s && s->n_calls >= 1 && s->time_row_host && s->c0_host && s->c1_host);
+    DIDI_CHECK_ARG(s->x0_f32 && s->workspace && s->kv_hi && s->ctx_mask);
+    if (s->euler) DIDI_CHECK_ARG(s->c2_host && s->x_state);
+    if (s->ids64) DIDI_CHECK_ARG(s->cls_hi && s->argmax_partial && s->x0_hi && s->V > 0);
+    if (s->ids64 && s->precision == DIDI_PREC_BF16X3) DIDI_CHECK_ARG(s->cls_lo && s->x0_lo);
+    if (!shapes_ok(dec, s->B, s->S, s->C)) return DIDI_ERR_UNSUPPORTED;
+    const size_t MH = (size_t)s->B * s->S * dec->H;
+    const uint64_t ctr_per_draw = MH / 4;
+
+    didi_forward_args f{};
+    f.B = s->B; f.S = s->S; f.C = s->C; f.precision = s->precision;
+    f.kv_hi = s->kv_hi; f.kv_lo = s->kv_lo; f.ctx_mask = s->ctx_mask;
+    f.workspace = s->workspace; f.workspace_bytes = s->workspace_bytes;
+    f.x0_f32 = s->x0_f32;
+    auto draw = [&](int i) -> const float* { return s->noise ? s->noise + (size_t)i * MH : nullptr; };
+
+    if (!s->euler) {
+        for (int k = 0; k < s->n_calls; ++k) {
+            didi_step_args& st = f.step;
+            st = didi_step_args{};
+            st.cin = 1.0f;
+            st.E = draw(k);
+            st.seed = s->seed; st.offset = s->base_offset + (uint64_t)k * ctr_per_draw;
+            if (k == 0) { st.mode = DIDI_STEP_INIT; st.ce = s->init_scale; }
+            else { st.mode = DIDI_STEP_DDPM; st.X0 = s->x0_f32; st.cx0 = s->c0_host[k - 1]; st.ce = s->c1_host[k - 1]; }
+            st.t = s->time_row_host[k];
+            st.xin_out = s->xt_trace ? s->xt_trace + (size_t)k * MH : nullptr;
+            const bool last = k == s->n_calls - 1;
+            f.x0_hi = last ? s->x0_hi : nullptr;
+            f.x0_lo = last ? s->x0_lo : nullptr;
+            TRY(didi_decoder_forward(dec, &f, stream));
+        }
+    } else {
+        didi_step_args init{};
+        init.mode = DIDI_STEP_INIT; init.M = s->B * s->S; init.S = s->S; init.H = dec->H;
+        init.E = draw(0); init.ce = s->init_scale; init.cin = 1.0f;
+        init.seed = s->seed; init.offset = s->base_offset;
+        init.x_out = s->x_state;
+        TRY(didi_step_embed_ln(&init, stream));
+        for (int k = 0; k < s->n_calls; ++k) {
+            didi_step_args& st = f.step;
+            st = didi_step_args{};
+            st.mode = DIDI_STEP_EULER;
+            st.X = s->x_state;
+            st.X0 = k == 0 ? s->x_state : s->x0_f32;
+            st.ratio = k == 0 ? 0.0f : s->c2_host[k - 1];
+            st.ce = s->c0_host[k];
+            st.cin = s->c1_host[k];
+            st.E = draw(k + 1);
+            st.seed = s->seed; st.offset = s->base_offset + (uint64_t)(k + 1) * ctr_per_draw;
+            st.x_out = s->x_state;
+            st.t = s->time_row_host[k];
+            st.xin_out = s->xt_trace ? s->xt_trace + (size_t)k * MH : nullptr;
+            f.x0_hi = nullptr; f.x0_lo = nullptr;
+            TRY(didi_decoder_forward(dec, &f, stream));
+        }
+        // final Euler update lands on sigma = 0 (src/sampling.py:80): x0 <- x + (x - x0_hat) * ratio
+        didi_step_args fin{};
+        fin.mode = DIDI_STEP_EULER; fin.M = s->B * s->S; fin.S = s->S; fin.H = dec->H;
+        fin.X = s->x_state; fin.X0 = s->x0_f32; fin.ratio = s->c2_host[s->n_calls - 1]; fin.ce = 0.f; fin.cin = 1.0f;
+        fin.x_out = s->x0_f32;
+        TRY(didi_step_embed_ln(&fin, stream));
+        if (s->x0_hi) TRY(didi_split_bf16(s->x0_f32, s->x0_hi, s->x0_lo, MH, stream));
+    }
+    if (s->ids64) {
+        TRY(didi_round_argmax(s->x0_hi, s->x0_lo, dec->H, s->cls_hi, s->cls_lo, dec->H, s->B * s->S, s->V, dec->H,
+                              s->precision, s->argmax_partial, s->ids64, nullptr, stream));
+    }
+    return DIDI_OK;
+}

@@ -1,0 +1,301 @@
+"""DiDiSampler: the sampler-visible part of reference ``DiDi`` (src/diffusion/model.py:66-198) on HIP.
+
+Same call surface as the reference module on this path:
+  * attributes ``emb, time_embeds, classifier, sigmas, diffusion_steps, s_churn, s_tmin, s_tmax,
+    sampling_mode, step_freq`` (model.py:92-127), read by ``sample`` (src/sampling.py:11-13,39,87-88);
+  * ``model(encoder_input_ids=, encoder_attention_mask=, decoder_inputs_embeds=, time_ids=,
+    context=) -> (x0_hat, context)`` with the reference's ``ValueError`` when neither ids nor
+    context is given (model.py:172-198).  ``context`` is returned and accepted back by reference.
+Weights come from a state dict in the reference's checkpoint key layout.
+
+Everything numeric runs in libdidi_hip (didi_amd/csrc) through didi_amd/ops.py and the engine
+entry points; torch only owns memory.  Weight packing at load time: q/k/v (and cross k/v) Linear
+weights are row-concatenated, then every matrix is split into bf16 hi/lo planes on the device.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib, ops
+from ._lib import lib
+from .config import DiDiConfig
+from .schedule import configure_schedule
+
+
+class _Planes:
+    """A Linear's packed weights: bf16 planes [N, K] + fp32 bias."""
+
+    def __init__(self, weight, bias, device):
+        w = weight.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.hi, self.lo = ops.split(w)
+        self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.N, self.K = w.shape
+
+    def c(self):
+        return _lib.Linear(self.hi.data_ptr(), self.lo.data_ptr(), _lib.ptr(self.bias), self.N, self.K)
+
+    def __call__(self, a_hi, a_lo, precision, **kw):
+        return ops.gemm(a_hi, a_lo, self.hi, self.lo, bias=self.bias, precision=precision, **kw)
+
+
+class _Embedding:
+    """``nn.Embedding`` stand-in (``.weight`` + gather); the gather is pure indexing."""
+
+    def __init__(self, weight):
+        self.weight = weight
+
+    def __call__(self, ids):
+        return ops.embed_gather(ids.reshape(-1, ids.shape[-1]), self.weight).reshape(*ids.shape, -1)
+
+
+class _Classifier:
+    """``nn.Linear(dec_dim, vocab, bias=False)`` stand-in (model.py:118): fp32 logits via the HIP GEMM."""
+
+    def __init__(self, planes, weight, owner):
+        self.planes, self.weight, self._owner = planes, weight, owner
+
+    def __call__(self, x):
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
+        hi, lo = ops.split(x2)
+        _, _, y = self.planes(hi, lo, self._owner.precision, out_f32=True, out_planes=False)
+        return y.reshape(*lead, -1)
+
+
+class DiDiSampler:
+    def __init__(self, state_dict, cfg: DiDiConfig, device="cuda", precision="bf16x3"):
+        if precision not in ops.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(ops.PRECISIONS)}")
+        self.cfg, self.device, self.precision = cfg, torch.device(device), precision
+        sd = state_dict
+        dev = self.device
+        f = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+        # attributes the sampler reads (model.py:92-127)
+        self.diffusion_steps = cfg.diffusion_steps
+        self.sampling_mode, self.step_freq, self.noise_factor = cfg.sampling_mode, cfg.step_freq, cfg.noise_factor
+        self.s_churn, self.s_tmin, self.s_tmax = cfg.s_churn, cfg.s_tmin, cfg.s_tmax
+        self.encoder_dim, self.decoder_dim, self.pad_idx = cfg.enc_dim, cfg.dec_dim, cfg.pad_idx
+        self.emb = _Embedding(f("emb.weight"))
+        self.time_embeds = _Embedding(f("time_embeds.weight"))
+        cls_w = self.emb.weight if cfg.tie_weights else f("classifier.weight")
+        self._cls = _Planes(cls_w, None, dev)
+        self.classifier = _Classifier(self._cls, cls_w, self)
+        if "sigmas" in sd:
+            self._sigmas_host = sd["sigmas"].detach().float().cpu()
+        else:
+            self._sigmas_host, _ = configure_schedule(cfg.diffusion_steps, cfg.schedule)
+        self.sigmas = self._sigmas_host.to(dev)
+        self._build_decoder(sd, f)
+        self._build_encoder(sd, f)
+        self._bufs = {}
+        self._ctx_key = None
+
+    # ------------------------------------------------------------------ decoder (engine structs)
+    def _build_decoder(self, sd, f):
+        cfg, dev = self.cfg, self.device
+        H = cfg.dec_dim
+        self._keep = []  # tensors referenced by raw pointer from the ctypes structs
+        layers = (_lib.DecoderLayer * cfg.dec_layers)()
+        for i in range(cfg.dec_layers):
+            p = f"decoder.encoder.layer.{i}."
+
+            def cat(block, names):
+                w = torch.cat([sd[f"{p}{block}.self.{n}.weight"] for n in names], 0)
+                b = torch.cat([sd[f"{p}{block}.self.{n}.bias"] for n in names], 0)
+                return _Planes(w, b, dev)
+
+            def lin(name):
+                return _Planes(sd[p + name + ".weight"], sd[p + name + ".bias"], dev)
+
+            parts = dict(
+                qkv=cat("attention", ("query", "key", "value")), attn_out=lin("attention.output.dense"),
+                cq=cat("crossattention", ("query",)), ckv=cat("crossattention", ("key", "value")),
+                cross_out=lin("crossattention.output.dense"), ffn_up=lin("intermediate.dense"), ffn_down=lin("output.dense"),
+            )
+            lns = dict(ln1=p + "attention.output.LayerNorm", ln2=p + "crossattention.output.LayerNorm", ln3=p + "output.LayerNorm")
+            ly = layers[i]
+            for k, v in parts.items():
+                setattr(ly, k, v.c())
+                self._keep.append(v)
+            for k, name in lns.items():
+                g, b = f(name + ".weight"), f(name + ".bias")
+                setattr(ly, k + "_g", g.data_ptr())
+                setattr(ly, k + "_b", b.data_ptr())
+                self._keep += [g, b]
+        self._pos = f("decoder.embeddings.position_embeddings.weight")
+        self._tok0 = f("decoder.embeddings.token_type_embeddings.weight")[0].contiguous()
+        self._eln_g, self._eln_b = f("decoder.embeddings.LayerNorm.weight"), f("decoder.embeddings.LayerNorm.bias")
+        d = _lib.Decoder()
+        d.H, d.heads, d.I, d.L, d.ln_eps = H, cfg.dec_heads, cfg.dec_ffn, cfg.dec_layers, cfg.dec_ln_eps
+        d.time_embeds, d.pos_emb, d.tok_type0 = self.time_embeds.weight.data_ptr(), self._pos.data_ptr(), self._tok0.data_ptr()
+        d.emb_ln_g, d.emb_ln_b = self._eln_g.data_ptr(), self._eln_b.data_ptr()
+        d.layers_host = C.cast(layers, C.POINTER(_lib.DecoderLayer))
+        self._layers, self._dec = layers, d
+
+    # ------------------------------------------------------------------ context encoder (cold path: once per batch)
+    def _build_encoder(self, sd, f):
+        cfg, dev = self.cfg, self.device
+        e = {}
+        if cfg.enc_kind == "blenderbot":
+            e["tok"], e["pos"] = f("encoder.embed_tokens.weight"), f("encoder.embed_positions.weight")
+            e["layers"] = []
+            for i in range(cfg.enc_layers):
+                p = f"encoder.layers.{i}."
+                qkv_w = torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+                qkv_b = torch.cat([sd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+                e["layers"].append(dict(
+                    ln1=(f(p + "self_attn_layer_norm.weight"), f(p + "self_attn_layer_norm.bias")),
+                    qkv=_Planes(qkv_w, qkv_b, dev),
+                    out=_Planes(sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"], dev),
+                    ln2=(f(p + "final_layer_norm.weight"), f(p + "final_layer_norm.bias")),
+                    fc1=_Planes(sd[p + "fc1.weight"], sd[p + "fc1.bias"], dev),
+                    fc2=_Planes(sd[p + "fc2.weight"], sd[p + "fc2.bias"], dev),
+                ))
+            e["ln_f"] = (f("encoder.layer_norm.weight"), f("encoder.layer_norm.bias"))
+        elif cfg.enc_kind == "bert":
+            q = "encoder.embeddings."
+            e["tok"], e["pos"] = f(q + "word_embeddings.weight"), f(q + "position_embeddings.weight")
+            e["tok0"] = f(q + "token_type_embeddings.weight")[0].contiguous()
+            e["eln"] = (f(q + "LayerNorm.weight"), f(q + "LayerNorm.bias"))
+            e["zero_row"] = torch.zeros(1, cfg.enc_dim, device=dev)
+            e["layers"] = []
+            for i in range(cfg.enc_layers):
+                p = f"encoder.encoder.layer.{i}."
+                qkv_w = torch.cat([sd[p + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0)
+                qkv_b = torch.cat([sd[p + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], 0)
+                e["layers"].append(dict(
+                    qkv=_Planes(qkv_w, qkv_b, dev),
+                    out=_Planes(sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"], dev),
+                    ln1=(f(p + "attention.output.LayerNorm.weight"), f(p + "attention.output.LayerNorm.bias")),
+                    fc1=_Planes(sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"], dev),
+                    fc2=_Planes(sd[p + "output.dense.weight"], sd[p + "output.dense.bias"], dev),
+                    ln2=(f(p + "output.LayerNorm.weight"), f(p + "output.LayerNorm.bias")),
+                ))
+        else:
+            raise ValueError(f"Unsupported encoder kind: {cfg.enc_kind}")
+        if cfg.has_adapter:  # model.py:122-123
+            e["ad0"] = _Planes(sd["adapter.0.weight"], sd["adapter.0.bias"], dev)
+            e["ad2"] = _Planes(sd["adapter.2.weight"], sd["adapter.2.bias"], dev)
+        self._enc = e
+
+    def _encode_context(self, input_ids, attention_mask):
+        """``DiDi._encode_context`` (model.py:165-170): encoder last_hidden_state (+ adapter) -> fp32 [B, C, H]."""
+        cfg, e, P = self.cfg, self._enc, "bf16x3"  # cold path (1 of ~2000 calls): always fp32-class
+        B, Cn = input_ids.shape
+        E, A = cfg.enc_dim, cfg.enc_heads
+        mask32 = attention_mask.to(torch.int32).contiguous()
+
+        def attn(qkv_hi, qkv_lo):
+            v = lambda t, i: None if t is None else t.view(B, Cn, 3 * E)[:, :, i * E:(i + 1) * E]  # noqa: E731
+            q, k, vv = ((v(qkv_hi, i), v(qkv_lo, i)) for i in range(3))
+            o_hi, o_lo = ops.attention(q, k, vv, A, causal=False, key_mask=mask32, precision=P)
+            return o_hi.view(B * Cn, E), o_lo.view(B * Cn, E)
+
+        if cfg.enc_kind == "blenderbot":
+            scale = math.sqrt(E) if cfg.enc_scale_embedding else 1.0
+            h = ops.embed_gather(input_ids, e["tok"], scale, e["pos"]).view(B * Cn, E)
+            for ly in e["layers"]:
+                y_hi, y_lo, _ = ops.layernorm(h, *ly["ln1"], cfg.enc_ln_eps)
+                qkv_hi, qkv_lo, _ = ly["qkv"](y_hi, y_lo, P)
+                a_hi, a_lo = attn(qkv_hi, qkv_lo)
+                _, _, h = ly["out"](a_hi, a_lo, P, residual=h, out_f32=True, out_planes=False)
+                y_hi, y_lo, _ = ops.layernorm(h, *ly["ln2"], cfg.enc_ln_eps)
+                f_hi, f_lo, _ = ly["fc1"](y_hi, y_lo, P, act="gelu")
+                _, _, h = ly["fc2"](f_hi, f_lo, P, residual=h, out_f32=True, out_planes=False)
+            c_hi, c_lo, ctx = ops.layernorm(h, *e["ln_f"], cfg.enc_ln_eps, f32=True)
+        else:
+            x = ops.embed_gather(input_ids, e["tok"]).view(B * Cn, E)
+            h_hi = torch.empty((B * Cn, E), dtype=torch.bfloat16, device=self.device)
+            h_lo = torch.empty_like(h_hi)
+            ops.step_embed_ln(_lib.STEP_NONE, B * Cn, Cn, E, X=x, time_embeds=e["zero_row"], t=0, pos_emb=e["pos"],
+                              tok_type0=e["tok0"], ln_gamma=e["eln"][0], ln_beta=e["eln"][1], ln_eps=1e-12, h_hi=h_hi, h_lo=h_lo)
+            ctx = None
+            for ly in e["layers"]:
+                qkv_hi, qkv_lo, _ = ly["qkv"](h_hi, h_lo, P)
+                a_hi, a_lo = attn(qkv_hi, qkv_lo)
+                _, _, t = ly["out"](a_hi, a_lo, P, residual_planes=(h_hi, h_lo), out_f32=True, out_planes=False)
+                h_hi, h_lo, _ = ops.layernorm(t, *ly["ln1"], 1e-12)
+                f_hi, f_lo, _ = ly["fc1"](h_hi, h_lo, P, act="gelu")
+                _, _, t = ly["fc2"](f_hi, f_lo, P, residual_planes=(h_hi, h_lo), out_f32=True, out_planes=False)
+                h_hi, h_lo, ctx = ops.layernorm(t, *ly["ln2"], 1e-12, f32=True)
+            c_hi, c_lo = h_hi, h_lo
+        if cfg.has_adapter:
+            t_hi, t_lo, _ = e["ad0"](c_hi, c_lo, P, act="tanh")
+            _, _, ctx = e["ad2"](t_hi, t_lo, P, out_f32=True, out_planes=False)
+        return ctx.view(B, Cn, cfg.dec_dim)
+
+    # ------------------------------------------------------------------ buffers + hoisted cross K/V
+    @property
+    def prec(self):
+        return ops.PRECISIONS[self.precision]
+
+    def buffers(self, B, S, Cn):
+        key = (B, S, Cn)
+        b = self._bufs.get(key)
+        if b is None:
+            dev, H = self.device, self.cfg.dec_dim
+            ws_bytes = lib.didi_decoder_workspace_bytes(C.byref(self._dec), B, S, Cn)
+            if ws_bytes == 0:
+                raise _lib.DidiHipError(f"unsupported decoder shape B={B} S={S} C={Cn} H={H} heads={self.cfg.dec_heads}")
+            kv_bytes = lib.didi_decoder_kv_plane_bytes(C.byref(self._dec), B, Cn)
+            b = dict(
+                ws=torch.empty(ws_bytes, dtype=torch.uint8, device=dev), ws_bytes=ws_bytes,
+                kv_hi=torch.empty(kv_bytes, dtype=torch.uint8, device=dev),
+                kv_lo=torch.empty(kv_bytes, dtype=torch.uint8, device=dev),
+                x0=torch.empty((B, S, H), dtype=torch.float32, device=dev),
+                x0_hi=torch.empty((B * S, H), dtype=torch.bfloat16, device=dev),
+                x0_lo=torch.empty((B * S, H), dtype=torch.bfloat16, device=dev),
+                x_state=torch.empty((B, S, H), dtype=torch.float32, device=dev),
+                partial=torch.empty(lib.didi_round_argmax_bytes(B * S, self.cfg.vocab), dtype=torch.uint8, device=dev),
+            )
+            self._bufs = {key: b}  # keep one shape resident
+            self._ctx_key = None
+        return b
+
+    def prepare_context(self, context, attention_mask, S):
+        """Hoist the cross-attention K/V of ``context`` for all layers; cached per context tensor."""
+        B, Cn, _ = context.shape
+        b = self.buffers(B, S, Cn)
+        key = (context.data_ptr(), context._version, attention_mask.data_ptr(), attention_mask._version, B, S, Cn)
+        if self._ctx_key != key:
+            ctx = context.contiguous().float()
+            b["mask32"] = attention_mask.to(torch.int32).contiguous()
+            _lib.check(lib.didi_decoder_prepare_context(C.byref(self._dec), ctx.data_ptr(), B, Cn, self.prec, b["ws"].data_ptr(),
+                                                        b["ws_bytes"], b["kv_hi"].data_ptr(), b["kv_lo"].data_ptr(),
+                                                        _lib.current_stream()), "prepare_context")
+            self._ctx_key = key
+            self._ctx_ref = (context, attention_mask)  # keep alive: the key holds raw addresses
+        return b
+
+    # ------------------------------------------------------------------ DiDi.forward
+    def __call__(self, encoder_input_ids=None, encoder_attention_mask=None, decoder_inputs_embeds=None, time_ids=None,
+                 context=None):
+        if encoder_input_ids is None and context is None:
+            raise ValueError("Either `encoder_input_ids` or `context` must be provided.")
+        if context is None:
+            context = self._encode_context(encoder_input_ids, encoder_attention_mask)
+        x = decoder_inputs_embeds.to(self.device).contiguous().float()
+        B, S, H = x.shape
+        b = self.prepare_context(context, encoder_attention_mask, S)
+        tidx = time_ids.reshape(-1).to(device=self.device, dtype=torch.int32).contiguous()
+        if tidx.numel() == 1:
+            tidx = tidx.expand(B).contiguous()
+        out = torch.empty_like(x)
+        fa = _lib.ForwardArgs()
+        fa.B, fa.S, fa.C, fa.precision = B, S, context.shape[1], self.prec
+        fa.step.mode, fa.step.X, fa.step.cin, fa.step.time_idx = _lib.STEP_NONE, x.data_ptr(), 1.0, tidx.data_ptr()
+        fa.kv_hi, fa.kv_lo, fa.ctx_mask = b["kv_hi"].data_ptr(), b["kv_lo"].data_ptr(), b["mask32"].data_ptr()
+        fa.workspace, fa.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
+        fa.x0_f32 = out.data_ptr()
+        _lib.check(lib.didi_decoder_forward(C.byref(self._dec), C.byref(fa), _lib.current_stream()), "decoder_forward")
+        return out, context
+
+    forward = __call__
+
+    def eval(self):
+        return self
+
+    @classmethod
+    def from_state_dict(cls, state_dict, cfg, **kw):
+        return cls(state_dict, cfg, **kw)

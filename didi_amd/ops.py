@@ -1,0 +1,143 @@
+"""Tensor-level wrappers over the C ABI (one per entry point).
+
+torch here is plumbing only: it owns device memory and the current HIP stream; every function
+below passes raw device pointers to libdidi_hip and returns torch tensors that alias the outputs.
+Nothing falls back to eager torch arithmetic.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib
+
+PRECISIONS = {"bf16": _lib.PREC_BF16, "bf16x3": _lib.PREC_BF16X3}
+ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "gelu": _lib.ACT_GELU, "tanh": _lib.ACT_TANH}
+
+
+def _prec(p):
+    return PRECISIONS[p] if isinstance(p, str) else int(p)
+
+
+def _f32c(t):
+    assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda, (t.dtype, t.is_contiguous(), t.device)
+    return t
+
+
+def split(x, need_lo=True):
+    """fp32 tensor -> (hi, lo) bf16 planes of the same shape."""
+    x = _f32c(x)
+    hi = torch.empty_like(x, dtype=torch.bfloat16)
+    lo = torch.empty_like(x, dtype=torch.bfloat16) if need_lo else None
+    _lib.check(lib.didi_split_bf16(x.data_ptr(), hi.data_ptr(), _lib.ptr(lo), x.numel(), _lib.current_stream()), "split")
+    return hi, lo
+
+
+def join(hi, lo=None):
+    """Test helper: planes -> fp32 (torch arithmetic; never used on the product path)."""
+    return hi.float() if lo is None else hi.float() + lo.float()
+
+
+def philox_normal(shape, seed, offset=0, device="cuda"):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    _lib.check(lib.didi_philox_normal(out.data_ptr(), out.numel(), seed, offset, _lib.current_stream()), "philox")
+    return out
+
+
+def embed_gather(ids, table, scale=1.0, pos=None):
+    """ids int64 [B, S] -> fp32 [B, S, H] = table[ids] * scale (+ pos[s])."""
+    B, S = ids.shape
+    H = table.shape[1]
+    ids = ids.contiguous()
+    out = torch.empty((B, S, H), dtype=torch.float32, device=ids.device)
+    _lib.check(lib.didi_embed_gather(ids.data_ptr(), table.data_ptr(), scale, _lib.ptr(pos), B * S, S, H, out.data_ptr(),
+                                     _lib.current_stream()), "embed_gather")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, planes=True, need_lo=True, f32=False):
+    x = _f32c(x)
+    M, H = x.numel() // x.shape[-1], x.shape[-1]
+    hi = torch.empty_like(x, dtype=torch.bfloat16) if planes else None
+    lo = torch.empty_like(x, dtype=torch.bfloat16) if planes and need_lo else None
+    y = torch.empty_like(x) if f32 else None
+    _lib.check(lib.didi_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, M, H, _lib.ptr(hi), _lib.ptr(lo),
+                                  _lib.ptr(y), _lib.current_stream()), "layernorm")
+    return hi, lo, y
+
+
+def gemm(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, precision="bf16x3", residual=None, residual_planes=None,
+         out_f32=False, out_planes=True, out_lo=True):
+    """C = act(A W^T + bias) + residual.  A planes [M,K], W planes [N,K].  -> (C_hi, C_lo, C_f32)."""
+    M, K = a_hi.shape
+    N = w_hi.shape[0]
+    dev = a_hi.device
+    g = _lib.GemmArgs()
+    g.M, g.N, g.K, g.precision = M, N, K, _prec(precision)
+    g.A_hi, g.A_lo, g.lda = a_hi.data_ptr(), _lib.ptr(a_lo), a_hi.stride(0)
+    g.W_hi, g.W_lo, g.ldw = w_hi.data_ptr(), _lib.ptr(w_lo), w_hi.stride(0)
+    g.bias, g.act = _lib.ptr(bias), ACTS[act]
+    if residual is not None:
+        g.R_f32, g.ldr = _f32c(residual).data_ptr(), residual.stride(0)
+    if residual_planes is not None:
+        g.R_hi, g.R_lo, g.ldr = residual_planes[0].data_ptr(), _lib.ptr(residual_planes[1]), residual_planes[0].stride(0)
+    c_f32 = torch.empty((M, N), dtype=torch.float32, device=dev) if out_f32 else None
+    c_hi = torch.empty((M, N), dtype=torch.bfloat16, device=dev) if out_planes else None
+    c_lo = torch.empty((M, N), dtype=torch.bfloat16, device=dev) if out_planes and out_lo else None
+    g.C_f32, g.C_hi, g.C_lo, g.ldc = _lib.ptr(c_f32), _lib.ptr(c_hi), _lib.ptr(c_lo), N
+    _lib.check(lib.didi_gemm_bf16(C.byref(g), _lib.current_stream()), "gemm")
+    return c_hi, c_lo, c_f32
+
+
+def attention(q, k, v, heads, causal=False, key_mask=None, precision="bf16x3"):
+    """q/k/v: (hi, lo) plane pairs shaped [B, S, heads*D] (views with a row stride are fine)."""
+    B, Sq, HD = q[0].shape
+    Sk = k[0].shape[1]
+    a = _lib.AttnArgs()
+    a.B, a.heads, a.Sq, a.Sk, a.D = B, heads, Sq, Sk, HD // heads
+    a.precision, a.causal, a.key_mask = _prec(precision), int(causal), _lib.ptr(key_mask)
+    a.Q_hi, a.Q_lo, a.ldq = q[0].data_ptr(), _lib.ptr(q[1]), q[0].stride(1)
+    a.K_hi, a.K_lo, a.ldk = k[0].data_ptr(), _lib.ptr(k[1]), k[0].stride(1)
+    a.V_hi, a.V_lo, a.ldv = v[0].data_ptr(), _lib.ptr(v[1]), v[0].stride(1)
+    for t, s in ((q[0], Sq), (k[0], Sk), (v[0], Sk)):
+        assert t.stride(0) == s * t.stride(1) and t.stride(2) == 1, "planes must be [B*S, ld] row-major"
+    o_hi = torch.empty((B, Sq, HD), dtype=torch.bfloat16, device=q[0].device)
+    o_lo = torch.empty_like(o_hi) if a.precision == _lib.PREC_BF16X3 else None
+    a.O_hi, a.O_lo, a.ldo = o_hi.data_ptr(), _lib.ptr(o_lo), HD
+    _lib.check(lib.didi_attention(C.byref(a), _lib.current_stream()), "attention")
+    return o_hi, o_lo
+
+
+def round_argmax(x_hi, x_lo, w_hi, w_lo, precision="bf16x3"):
+    M, K = x_hi.shape
+    V = w_hi.shape[0]
+    partial = torch.empty(lib.didi_round_argmax_bytes(M, V), dtype=torch.uint8, device=x_hi.device)
+    ids = torch.empty(M, dtype=torch.int64, device=x_hi.device)
+    _lib.check(lib.didi_round_argmax(x_hi.data_ptr(), _lib.ptr(x_lo), x_hi.stride(0), w_hi.data_ptr(), _lib.ptr(w_lo),
+                                     w_hi.stride(0), M, V, K, _prec(precision), partial.data_ptr(), ids.data_ptr(), None,
+                                     _lib.current_stream()), "round_argmax")
+    return ids
+
+
+def first_eos(ids, eos_id):
+    B, S = ids.shape
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    lengths = torch.empty(B, dtype=torch.int32, device=ids.device)
+    _lib.check(lib.didi_first_eos(ids.data_ptr(), B, S, int(eos_id), lengths.data_ptr(), _lib.current_stream()), "first_eos")
+    return lengths
+
+
+def step_embed_ln(mode, M, S, H, *, X=None, X0=None, E=None, cx0=0.0, ce=0.0, ratio=0.0, cin=1.0, seed=0, offset=0,
+                  x_out=None, xin_out=None, time_embeds=None, t=0, time_idx=None, pos_emb=None, tok_type0=None,
+                  ln_gamma=None, ln_beta=None, ln_eps=1e-12, h_hi=None, h_lo=None):
+    a = _lib.StepArgs()
+    a.mode, a.M, a.S, a.H = mode, M, S, H
+    a.X, a.X0, a.E = _lib.ptr(X), _lib.ptr(X0), _lib.ptr(E)
+    a.cx0, a.ce, a.ratio, a.cin = cx0, ce, ratio, cin
+    a.seed, a.offset = seed, offset
+    a.x_out, a.xin_out = _lib.ptr(x_out), _lib.ptr(xin_out)
+    a.time_embeds, a.t, a.time_idx = _lib.ptr(time_embeds), t, _lib.ptr(time_idx)
+    a.pos_emb, a.tok_type0, a.ln_gamma, a.ln_beta, a.ln_eps = (_lib.ptr(pos_emb), _lib.ptr(tok_type0), _lib.ptr(ln_gamma),
+                                                               _lib.ptr(ln_beta), ln_eps)
+    a.h_hi, a.h_lo = _lib.ptr(h_hi), _lib.ptr(h_lo)
+    _lib.check(lib.didi_step_embed_ln(C.byref(a), _lib.current_stream()), "step_embed_ln")

@@ -1,0 +1,304 @@
+/* libdidi_hip: C ABI of the MI355X-native DiDi sampler path.
+ *
+ * The reference (deepvk/didi) has NO native layer and no FFI: its sampler path is Python over
+ * torch/transformers.  The entry points below are what a binding for that path binds instead;
+ * each cites the reference lines whose device work it replaces (paths relative to the reference
+ * root; "HF:" = transformers, which holds the decoder arithmetic -- SURVEY.md section 8c).
+ * INTEGRATION.md shows the ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; `stream` is a hipStream_t
+ *     passed as void* (NULL = the default stream); all work is enqueued asynchronously on it.
+ *   - nothing here allocates, frees or synchronises; workspaces are sized by the *_bytes queries
+ *     and passed in.  No global mutable state: calls on different streams/devices are independent.
+ *   - return value: DIDI_OK (0) or a negative DIDI_ERR_* code.  No exceptions cross the boundary.
+ *   - "split planes": an fp32 tensor [R, W] held as two bf16 tensors hi,lo [R, W] with
+ *     value = hi + lo (hi = RNE bf16 of the value).  lo pointers may be NULL where stated: then
+ *     only hi is read/written ("bf16" precision); with both, GEMMs and attention add the hi*lo and
+ *     lo*hi cross products ("bf16x3", fp32-class accuracy on the bf16 MFMA pipe).
+ *   - gfx950 (MI355X) only.
+ */
+#ifndef DIDI_HIP_H
+#define DIDI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIDI_ABI_VERSION 1
+
+enum {
+    DIDI_OK = 0,
+    DIDI_ERR_BAD_ARG = -1,     /* NULL where required, size/alignment constraint violated */
+    DIDI_ERR_UNSUPPORTED = -2, /* shape outside what the kernels are built for */
+    DIDI_ERR_LAUNCH = -3,      /* hipLaunchKernel reported an error */
+    DIDI_ERR_WORKSPACE = -4    /* workspace too small */
+};
+
+enum { DIDI_PREC_BF16 = 1, DIDI_PREC_BF16X3 = 3 }; /* = MFMA passes per product */
+
+/* ABI version / error text (no reference counterpart). */
+int didi_version(void);
+const char* didi_error_string(int code);
+
+/* ---------------------------------------------------------------- elementwise / row kernels */
+
+/* fp32 [n] -> split planes.  Used once per weight matrix at load time and for the encoder
+ * context.  (No reference counterpart: the reference keeps fp32 everywhere.)  n % 4 == 0. */
+int didi_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, size_t n, void* stream);
+
+/* Standard-normal noise, Philox4x32-10 + Box-Muller, counter-based: element i of the call with
+ * (seed, offset) depends only on (seed, offset + i/4).  Replaces `noise.normal_(0, 1)`
+ * (src/sampling.py:54,74,79) and `torch.randn_like` (:13) in throughput mode; parity tests inject
+ * noise tensors instead.  n % 4 == 0. */
+int didi_philox_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* Fused sampler step + decoder prologue: ONE pass over the [M, H] state.
+ *   mode DIDI_STEP_INIT : x = ce * E                                   (sampling.py:13 [+ :42])
+ *   mode DIDI_STEP_DDPM : x = cx0 * X0 + ce * E                        (sampling.py:53-55,
+ *                         = scale_input(x0 + sigma*eps, sigma), cx0 = 1/sqrt(sigma^2+1), ce = sigma*cx0;
+ *                         src/diffusion/utils.py:30-31)
+ *   mode DIDI_STEP_EULER: x = (X + (X - X0) * ratio) + ce * E           (sampling.py:98-100 of the
+ *                         previous call, then utils.py:55-56 churn of this call)
+ *   mode DIDI_STEP_NONE : x = X                                         (caller-supplied x_t, DiDi.forward)
+ * then, if x_out != NULL, x is stored (fp32) (and cin * x to xin_out if that is not NULL), and
+ *   h = LayerNorm(cin * x + time_embeds[t] + token_type[0] + pos[s]) -> split planes h_hi, h_lo
+ * which is `decoder_inputs_embeds + time_embeds(time_ids)` (src/diffusion/model.py:190-191)
+ * followed by BertEmbeddings (HF:models/bert/modeling_bert.py:53-108; eps from the config).
+ * E == NULL with ce != 0 draws noise in-kernel (Philox, as didi_philox_normal with the same
+ * seed/offset).  time_idx (int32 [M/S], per dialog) may be NULL: then every row uses `t`.
+ * Row m is position s = m % S of dialog m / S.  H % 4 == 0, H <= 2048.
+ * The LayerNorm part is skipped when h_hi == NULL (final Euler update, sampling.py:80). */
+enum { DIDI_STEP_NONE = 0, DIDI_STEP_INIT = 1, DIDI_STEP_DDPM = 2, DIDI_STEP_EULER = 3 };
+typedef struct didi_step_args {
+    int mode;
+    int M, S, H;
+    const float* X;  /* [M,H] current state (EULER, NONE) */
+    const float* X0; /* [M,H] denoiser output x0_hat (DDPM, EULER) */
+    const float* E;  /* [M,H] injected noise or NULL */
+    float cx0, ce, ratio, cin;
+    uint64_t seed, offset; /* in-kernel Philox when E == NULL && ce != 0 */
+    float* x_out;          /* [M,H] or NULL; may alias X or X0 */
+    float* xin_out;        /* [M,H] or NULL: receives cin * x, the denoiser input (tests/trace) */
+    const float* time_embeds; /* [T+1, H] */
+    int t;                    /* row of time_embeds when time_idx == NULL */
+    const int32_t* time_idx;  /* [M/S] or NULL */
+    const float* pos_emb;     /* [>=S, H] decoder.embeddings.position_embeddings */
+    const float* tok_type0;   /* [H] decoder.embeddings.token_type_embeddings row 0 */
+    const float* ln_gamma;    /* [H] */
+    const float* ln_beta;     /* [H] */
+    float ln_eps;
+    uint16_t* h_hi; /* [M,H] or NULL to skip the embedding/LayerNorm part */
+    uint16_t* h_lo; /* [M,H] */
+} didi_step_args;
+int didi_step_embed_ln(const didi_step_args* a, void* stream);
+
+/* out[m, :] = table[ids[m], :] * scale (+ pos[m % S, :])  -- token-embedding gather of the context
+ * encoder: BlenderbotScaledWordEmbedding + learned positions
+ * (HF:models/blenderbot/modeling_blenderbot.py:88-98,497-503) or Bert word embeddings
+ * (HF:models/bert/modeling_bert.py:103; token-type/position/LayerNorm via didi_step_embed_ln).
+ * ids int64 [M]; table fp32 [V, H]; pos fp32 [>=S, H] or NULL; out fp32 [M, H].  H % 4 == 0. */
+int didi_embed_gather(const int64_t* ids, const float* table, float scale, const float* pos, int M, int S, int H,
+                      float* out, void* stream);
+
+/* y = LayerNorm(x) over the last dim of fp32 x [M, H] (torch.nn.LayerNorm semantics: biased
+ * variance, eps inside the sqrt).  Replaces BertSelfOutput/BertOutput.LayerNorm
+ * (HF:models/bert/modeling_bert.py:292,350) -- the dense+bias+residual part is the GEMM epilogue --
+ * and the encoder's pre-LN norms.  Outputs: split planes (y_hi required unless y_f32 given;
+ * y_lo may be NULL) and/or fp32 y_f32.  H % 4 == 0, H <= 2048. */
+int didi_layernorm(const float* x, const float* gamma, const float* beta, float eps, int M, int H,
+                   uint16_t* y_hi, uint16_t* y_lo, float* y_f32, void* stream);
+
+/* ---------------------------------------------------------------- GEMM (MFMA bf16) */
+
+/* C[M,N] = epilogue( sum_p A_p[M,K] * W_p[N,K]^T ), fp32 accumulation on
+ * v_mfma_f32_16x16x32_bf16.  W is an nn.Linear weight as stored ([out, in] = [N, K], K
+ * contiguous), pre-split into planes.  Replaces every nn.Linear on the path:
+ * Bert query/key/value/dense (HF:models/bert/modeling_bert.py:175-177,244,253-254,290,335,348),
+ * the adapter (src/diffusion/model.py:123), `classifier` (src/sampling.py:64,82).
+ *   precision : DIDI_PREC_BF16 (A_hi*W_hi) or DIDI_PREC_BF16X3 (+ A_hi*W_lo + A_lo*W_hi)
+ *   epilogue  : v = acc (+ bias[n]) ; v = act(v) ; v += residual[m,n]
+ *               act: 0 none, 1 exact-erf GELU (hidden_act="gelu"), 2 tanh
+ *               residual: fp32 [M, ldr] or split planes (hi+lo), or none
+ *   outputs   : any of fp32 C_f32 [M, ldc] and split planes C_hi/C_lo [M, ldc]
+ * Constraints: K % 8 == 0, N % 4 == 0, lda/ldw % 8 == 0, ldc % 4 == 0, pointers 16-byte aligned. */
+enum { DIDI_ACT_NONE = 0, DIDI_ACT_GELU = 1, DIDI_ACT_TANH = 2 };
+typedef struct didi_gemm_args {
+    int M, N, K;
+    int precision;
+    const uint16_t *A_hi, *A_lo; /* [M, lda] */
+    int lda;
+    const uint16_t *W_hi, *W_lo; /* [N, ldw] */
+    int ldw;
+    const float* bias; /* [N] or NULL */
+    int act;
+    const float* R_f32;          /* residual fp32 [M, ldr] or NULL */
+    const uint16_t *R_hi, *R_lo; /* residual split planes [M, ldr] or NULL */
+    int ldr;
+    float* C_f32;          /* or NULL */
+    uint16_t *C_hi, *C_lo; /* or NULL */
+    int ldc;
+} didi_gemm_args;
+int didi_gemm_bf16(const didi_gemm_args* a, void* stream);
+
+/* ids[m] = argmax_n sum_p X_p[m,:] . Wc_p[n,:]  -- the "rounding" step
+ * `model.classifier(x_0)` + `logits.argmax(-1)` (src/sampling.py:64,82,32) without ever writing
+ * the [M, V] logits.  First (lowest) index wins ties, as torch.argmax on CPU.  Two launches:
+ * a GEMM whose epilogue keeps a per-row running (max, index) over a chunk of vocabulary columns,
+ * then a reduction over chunks.  `partial` is a caller workspace of didi_round_argmax_bytes(M, V).
+ * ids64 (int64, what torch returns) and/or ids32 may be NULL (not both). K % 8 == 0. */
+size_t didi_round_argmax_bytes(int M, int V);
+int didi_round_argmax(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uint16_t* W_hi,
+                      const uint16_t* W_lo, int ldw, int M, int V, int K, int precision, void* partial,
+                      int64_t* ids64, int32_t* ids32, void* stream);
+
+/* lengths[b] = (index of first eos in ids[b, :]) + 1, or S when the row holds none:
+ * `truncate_predictions` (src/sampling.py:104-113) without its per-row D2H sync. */
+int didi_first_eos(const int64_t* ids, int B, int S, int64_t eos_id, int32_t* lengths, void* stream);
+
+/* ---------------------------------------------------------------- attention */
+
+/* O[b, q, head] = softmax(Q K^T / sqrt(D) + mask) V for one layer, all (dialog, head) pairs:
+ * `eager_attention_forward` as BertSelfAttention / BertCrossAttention call it
+ * (HF:models/bert/modeling_bert.py:111-136,164-203,230-279).
+ *   causal != 0 : key j visible to query i iff j <= i  (is_decoder=True, HF:...:696-702); Sk == Sq
+ *   key_mask    : int32 [B, Sk], 0 = padded key (encoder_attention_mask, src/diffusion/model.py:196),
+ *                 or NULL.  Masked scores take the most negative float, as HF's additive mask: a
+ *                 row whose keys are ALL masked yields the uniform average of V (4.30.2 eager
+ *                 behaviour), never NaN.
+ * Q/K/V/O are split planes addressed as plane[(b*S + s) * ld + head*D + d]; lo planes may be NULL
+ * together with precision DIDI_PREC_BF16.  D % 8 == 0, D <= 64; Sq, Sk <= 96 (dialogs are <= 84 tokens,
+ * README.md:48-49 of the reference); ld % 8 == 0. */
+typedef struct didi_attn_args {
+    int B, heads, Sq, Sk, D;
+    int precision;
+    int causal;
+    const int32_t* key_mask;
+    const uint16_t *Q_hi, *Q_lo;
+    int ldq;
+    const uint16_t *K_hi, *K_lo;
+    int ldk;
+    const uint16_t *V_hi, *V_lo;
+    int ldv;
+    uint16_t *O_hi, *O_lo;
+    int ldo;
+} didi_attn_args;
+int didi_attention(const didi_attn_args* a, void* stream);
+
+/* ---------------------------------------------------------------- decoder engine */
+
+typedef struct didi_linear {
+    const uint16_t* w_hi; /* [N, K] */
+    const uint16_t* w_lo; /* [N, K] (may be NULL if only DIDI_PREC_BF16 is ever used) */
+    const float* bias;    /* [N] or NULL */
+    int N, K;
+} didi_linear;
+
+/* One BertLayer with cross-attention (HF:models/bert/modeling_bert.py:354-416).  qkv and ckv are
+ * the row-concatenations [query;key;value] and [key;value] of the reference's separate Linears. */
+typedef struct didi_decoder_layer {
+    didi_linear qkv;       /* attention.self.{query,key,value}            [3H, H] */
+    didi_linear attn_out;  /* attention.output.dense                      [H, H]  */
+    const float *ln1_g, *ln1_b;
+    didi_linear cq;        /* crossattention.self.query                   [H, H]  */
+    didi_linear ckv;       /* crossattention.self.{key,value}             [2H, H] */
+    didi_linear cross_out; /* crossattention.output.dense                 [H, H]  */
+    const float *ln2_g, *ln2_b;
+    didi_linear ffn_up;    /* intermediate.dense                          [I, H]  */
+    didi_linear ffn_down;  /* output.dense                                [H, I]  */
+    const float *ln3_g, *ln3_b;
+} didi_decoder_layer;
+
+typedef struct didi_decoder {
+    int H, heads, I, L;
+    float ln_eps;
+    const float* time_embeds; /* [T+1, H]  DiDi.time_embeds (src/diffusion/model.py:105) */
+    const float* pos_emb;     /* [max_pos, H] */
+    const float* tok_type0;   /* [H] */
+    const float *emb_ln_g, *emb_ln_b;
+    const didi_decoder_layer* layers_host; /* HOST array of L layer records */
+} didi_decoder;
+
+/* Bytes of workspace didi_decoder_forward needs for a batch of B dialogs, S target and C context
+ * positions.  0 on unsupported shapes. */
+size_t didi_decoder_workspace_bytes(const didi_decoder* dec, int B, int S, int C);
+
+/* Bytes of ONE plane set of the hoisted cross-attention K/V cache: [L][B*C][2H] bf16. */
+size_t didi_decoder_kv_plane_bytes(const didi_decoder* dec, int B, int C);
+
+/* Cross-attention K/V of the (loop-invariant) context, computed ONCE per batch for all layers:
+ * kv[l] = ctx @ ckv_l^T + b.  The reference recomputes these in every one of its ~2000 denoiser
+ * calls (HF:models/bert/modeling_bert.py:252-254 via a fresh cache per call, :644-649).
+ * ctx is fp32 [B*C, H] as returned by DiDi._encode_context (src/diffusion/model.py:165-170).
+ * kv_lo may be NULL with DIDI_PREC_BF16. */
+int didi_decoder_prepare_context(const didi_decoder* dec, const float* ctx, int B, int C, int precision,
+                                 void* workspace, size_t workspace_bytes, uint16_t* kv_hi, uint16_t* kv_lo,
+                                 void* stream);
+
+/* One denoiser call = DiDi.forward with a cached context (src/diffusion/model.py:172-198 with
+ * context != None) fused with the sampler update that produces its input:
+ *   [x <- step(...)]  ->  time-embedding + BertEmbeddings  ->  L x BertLayer  ->  x0_hat.
+ * `step` describes the input (see didi_step_embed_ln; its h_hi/h_lo/embedding fields are filled in
+ * by the engine from `dec`, only mode/X/X0/E/coefficients/seed/x_out/t/time_idx are read).
+ * Outputs: x0_f32 [B*S, H] (required) and, for the rounding kernel, split planes x0_hi/x0_lo
+ * (may be NULL).  The pooler (HF:...:680) and the per-call KV cache (:644-649) are dead code on
+ * this path and are not computed. */
+typedef struct didi_forward_args {
+    int B, S, C;
+    int precision;
+    didi_step_args step;
+    const uint16_t *kv_hi, *kv_lo; /* from didi_decoder_prepare_context */
+    const int32_t* ctx_mask;       /* [B, C] int32 */
+    void* workspace;
+    size_t workspace_bytes;
+    float* x0_f32;
+    uint16_t *x0_hi, *x0_lo;
+} didi_forward_args;
+int didi_decoder_forward(const didi_decoder* dec, const didi_forward_args* a, void* stream);
+
+/* The whole reverse-diffusion loop of sample_ddpm / sample_euler (src/sampling.py:38-101) for one
+ * batch, enqueued back to back with no host round trip: n_calls denoiser calls driven by the
+ * host-side plan rows (didi_amd/schedule.py), the rounding argmax at the end when ids64 != NULL,
+ * logits via didi_gemm_bf16 by the caller otherwise.
+ *   euler == 0: ddpm.  plan rows: time_row[k], c0[k] = a_k, c1[k] = b_k        (k = 0..n_calls-1)
+ *   euler != 0:        plan rows: time_row[k], c0[k] = churn_k, c1[k] = c_in_k, c2[k] = ratio_k
+ *   init_scale: x_T = init_scale * eps_0 (ddpm: already includes scale_input(., sigma_T))
+ * Noise: `noise` NULL -> in-kernel Philox (seed, call k uses offset = base_offset + k * M*H/4);
+ *        else fp32 [n_draws, M, H] in the reference's draw order (draw 0 = x_T; ddpm: draw k+1
+ *        follows call k, n_draws = n_calls; euler: draw k+1 precedes call k, n_draws = n_calls+1).
+ * xt_trace: NULL or fp32 [n_calls, M, H]; receives the denoiser input x_t of every call (tests).
+ * x_state: fp32 [M, H] scratch (euler state); x0_f32 receives the final x0 estimate
+ * (ddpm: x0_hat of the last call; euler: the final Euler update). */
+typedef struct didi_sample_args {
+    int B, S, C;
+    int precision;
+    int euler;
+    int n_calls;
+    const int32_t* time_row_host;
+    const float *c0_host, *c1_host, *c2_host;
+    float init_scale;
+    const float* noise;
+    uint64_t seed, base_offset;
+    float* xt_trace;
+    const uint16_t *kv_hi, *kv_lo;
+    const int32_t* ctx_mask;
+    void* workspace;
+    size_t workspace_bytes;
+    float* x_state;
+    float* x0_f32;
+    uint16_t *x0_hi, *x0_lo;
+    /* rounding (optional): classifier planes [V, H]; ids64 [B*S]; partial workspace */
+    const uint16_t *cls_hi, *cls_lo;
+    int V;
+    void* argmax_partial;
+    int64_t* ids64;
+} didi_sample_args;
+int didi_sample(const didi_decoder* dec, const didi_sample_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIDI_HIP_H */

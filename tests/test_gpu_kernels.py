@@ -1,0 +1,322 @@
+"""GPU parity tests of every C-ABI kernel entry point against fp64/fp32 torch-CPU references.
+
+Tolerances (stated per test):
+  * bf16 mode   : compared with the SAME bf16-rounded operands multiplied in fp64 -> only the
+                  fp32 accumulation order differs: rel-L2 <= 2e-5.
+  * bf16x3 mode : compared with the un-rounded fp32 operands in fp64: rel-L2 <= 3e-5 (the split
+                  representation carries ~16 mantissa bits; the lo*lo term is dropped).
+  * integer outputs (argmax ids, eos lengths, raw Philox stream): exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from didi_amd import ops as o
+
+    return o
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------ split
+def test_split_planes(ops):
+    x = rnd(1000, 128, seed=1, scale=3.0)
+    x[0, :4] = torch.tensor([0.0, -0.0, 1e-30, 65504.0])
+    hi, lo = ops.split(x.cuda())
+    assert torch.equal(hi.cpu(), x.to(torch.bfloat16)), "hi plane must be RNE bf16 of the value"
+    back = ops.join(hi, lo).cpu()
+    err = (back - x).abs() / x.abs().clamp_min(1e-20)
+    assert err.max().item() <= 2.0**-15, err.max().item()
+
+
+# ------------------------------------------------------------------ philox
+def test_philox_matches_oracle(ops):
+    from oracle.philox import normal
+
+    n, seed, off = 1 << 16, 0xC0FFEE1234, 977
+    z = ops.philox_normal((n,), seed, off).cpu().numpy()
+    want = normal(n, seed, off)
+    # same raw 32-bit stream; device logf/sincosf differ from numpy by a few ulp
+    assert np.abs(z - want).max() <= 5e-5, np.abs(z - want).max()
+    z2 = ops.philox_normal((n // 2,), seed, off + n // 8).cpu().numpy()
+    assert np.array_equal(z2, z[n // 2:]), "counter-based: a later offset must reproduce the tail"
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+
+
+# ------------------------------------------------------------------ layernorm / gather
+@pytest.mark.parametrize("M,H", [(7, 128), (184, 128), (33, 768), (5, 1280), (9, 96), (3, 2048)])
+def test_layernorm(ops, M, H):
+    x = rnd(M, H, seed=M + H, scale=2.0) + 0.5
+    g, b = 1 + rnd(H, seed=1, scale=0.1), rnd(H, seed=2, scale=0.1)
+    want = torch.nn.functional.layer_norm(x.double(), (H,), g.double(), b.double(), 1e-12)
+    hi, lo, y = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-12, f32=True)
+    assert rel_l2(y, want) <= 1e-6
+    assert rel_l2(ops.join(hi, lo), want) <= 2e-5
+    assert torch.equal(hi.cpu(), y.cpu().to(torch.bfloat16))
+
+
+def test_embed_gather(ops):
+    table, pos = rnd(50, 96, seed=3), rnd(12, 96, seed=4)
+    ids = torch.randint(0, 50, (3, 12), generator=torch.Generator().manual_seed(5))
+    out = ops.embed_gather(ids.cuda(), table.cuda(), 9.5, pos.cuda()).cpu()
+    assert torch.allclose(out, table[ids] * 9.5 + pos[None], rtol=1e-6, atol=1e-6)
+    out = ops.embed_gather(ids.cuda(), table.cuda()).cpu()
+    assert torch.equal(out, table[ids])
+
+
+# ------------------------------------------------------------------ fused step + embedding + LN
+@pytest.mark.parametrize("H", [128, 768])
+def test_step_embed_ln_modes(ops, H):
+    from didi_amd import _lib
+
+    B, S, T = 3, 11, 20
+    M = B * S
+    X, X0, E = rnd(M, H, seed=1, scale=50.0), rnd(M, H, seed=2), rnd(M, H, seed=3)
+    temb, pos, tok = rnd(T + 1, H, seed=4), rnd(S + 3, H, seed=5, scale=0.1), rnd(H, seed=6, scale=0.1)
+    g, b = 1 + rnd(H, seed=7, scale=0.1), rnd(H, seed=8, scale=0.1)
+    tidx = torch.tensor([3, 20, 1], dtype=torch.int32)
+    dev = lambda t: t.cuda()  # noqa: E731
+    cases = [
+        (_lib.STEP_INIT, dict(ce=7034.0 / 7034.1), lambda: (7034.0 / 7034.1) * E),
+        (_lib.STEP_DDPM, dict(cx0=0.6, ce=0.8), lambda: 0.6 * X0 + 0.8 * E),
+        (_lib.STEP_EULER, dict(ratio=-0.25, ce=0.3, cin=0.02), lambda: (X + (X - X0) * -0.25) + 0.3 * E),
+        (_lib.STEP_NONE, dict(), lambda: X),
+    ]
+    for mode, kw, ref in cases:
+        for per_row_t in (False, True):
+            x_ref = ref().double()
+            cin = kw.get("cin", 1.0)
+            t_rows = tidx.long().repeat_interleave(S) if per_row_t else torch.full((M,), 5)
+            pre = cin * x_ref + temb.double()[t_rows] + tok.double() + pos.double()[:S].repeat(B, 1)
+            want = torch.nn.functional.layer_norm(pre, (H,), g.double(), b.double(), 1e-12)
+            x_out = torch.empty(M, H, device="cuda")
+            xin = torch.empty(M, H, device="cuda")
+            h_hi = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
+            h_lo = torch.empty_like(h_hi)
+            ops.step_embed_ln(mode, M, S, H, X=dev(X), X0=dev(X0), E=dev(E), x_out=x_out, xin_out=xin,
+                              time_embeds=dev(temb), t=5, time_idx=dev(tidx) if per_row_t else None, pos_emb=dev(pos),
+                              tok_type0=dev(tok), ln_gamma=dev(g), ln_beta=dev(b), ln_eps=1e-12, h_hi=h_hi, h_lo=h_lo,
+                              cx0=kw.get("cx0", 0.0), ce=kw.get("ce", 0.0), ratio=kw.get("ratio", 0.0), cin=cin)
+            assert rel_l2(x_out, x_ref) <= 1e-6, (mode, per_row_t)
+            assert rel_l2(xin, cin * x_ref) <= 1e-6
+            assert rel_l2(ops.join(h_hi, h_lo), want) <= 3e-5, (mode, per_row_t)
+
+
+def test_step_in_kernel_philox_matches_standalone(ops):
+    from didi_amd import _lib
+
+    M, S, H = 8, 4, 128
+    seed, off = 99, 12345
+    x_out = torch.empty(M, H, device="cuda")
+    ops.step_embed_ln(_lib.STEP_INIT, M, S, H, ce=2.0, seed=seed, offset=off, x_out=x_out)
+    z = ops.philox_normal((M * H,), seed, off).view(M, H)
+    assert torch.equal(x_out, 2.0 * z)
+
+
+# ------------------------------------------------------------------ GEMM
+def _gemm_ref(a, w, bias, act, resid):
+    v = a.double() @ w.double().t()
+    if bias is not None:
+        v = v + bias.double()
+    if act == "gelu":
+        v = torch.nn.functional.gelu(v)
+    elif act == "tanh":
+        v = torch.tanh(v)
+    if resid is not None:
+        v = v + resid.double()
+    return v
+
+
+@pytest.mark.parametrize("M,N,K", [(184, 384, 128), (1, 128, 128), (130, 600, 128), (257, 8008, 128), (64, 288, 96),
+                                   (300, 768, 768), (200, 768, 3072), (129, 2304, 768), (50, 768, 1280)])
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_gemm_plain(ops, M, N, K, precision):
+    a, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
+    a_hi, a_lo = ops.split(a.cuda())
+    w_hi, w_lo = ops.split(w.cuda())
+    c_hi, c_lo, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), precision=precision, out_f32=True)
+    if precision == "bf16":
+        want = _gemm_ref(a_hi.cpu().float(), w_hi.cpu().float(), bias, None, None)
+        tol = 2e-5
+    else:
+        want = _gemm_ref(a, w, bias, None, None)
+        tol = 3e-5
+    assert rel_l2(c, want) <= tol, rel_l2(c, want)
+    assert (c.cpu().double() - want).abs().max().item() <= 50 * tol * want.abs().max().item()
+    assert rel_l2(ops.join(c_hi, c_lo), c) <= 2e-5
+    assert torch.equal(c_hi.cpu(), c.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("act", [None, "gelu", "tanh"])
+@pytest.mark.parametrize("resid", [None, "f32", "planes"])
+def test_gemm_epilogues(ops, act, resid):
+    M, N, K = 150, 256, 192
+    a, w, bias, r = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.1), rnd(N, seed=6), rnd(M, N, seed=7)
+    a_hi, a_lo = ops.split(a.cuda())
+    w_hi, w_lo = ops.split(w.cuda())
+    kw = {}
+    r_used = None
+    if resid == "f32":
+        kw["residual"], r_used = r.cuda(), r
+    elif resid == "planes":
+        kw["residual_planes"] = ops.split(r.cuda())
+        r_used = ops.join(*kw["residual_planes"]).cpu()
+    _, _, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), act=act, precision="bf16x3", out_f32=True, out_planes=False, **kw)
+    want = _gemm_ref(a, w, bias, act, r_used)
+    assert rel_l2(c, want) <= 3e-5, rel_l2(c, want)
+    # no bias
+    _, _, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, precision="bf16x3", out_f32=True, out_planes=False)
+    assert rel_l2(c, _gemm_ref(a, w, None, None, None)) <= 3e-5
+
+
+def test_gemm_identity_asymmetric(ops):
+    """A = I with an asymmetric W: catches a transposed or permuted C write (exact integers)."""
+    K = 128
+    a = torch.eye(K)
+    w = (torch.arange(192 * K, dtype=torch.float32).reshape(192, K) % 251) - 125  # exact in bf16
+    a_hi, a_lo = ops.split(a.cuda())
+    w_hi, w_lo = ops.split(w.cuda())
+    _, _, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, precision="bf16", out_f32=True, out_planes=False)
+    assert torch.equal(c.cpu(), w.t().contiguous())
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from didi_amd._lib import DidiHipError
+
+    a_hi, a_lo = ops.split(rnd(8, 20).cuda())
+    w_hi, w_lo = ops.split(rnd(8, 20).cuda())
+    with pytest.raises(DidiHipError):
+        ops.gemm(a_hi, a_lo, w_hi, w_lo)  # K % 8 != 0
+
+
+# ------------------------------------------------------------------ rounding (classifier + argmax)
+@pytest.mark.parametrize("M,V,K", [(184, 8008, 128), (77, 600, 128), (300, 8008, 768), (5, 130, 64)])
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_round_argmax(ops, M, V, K, precision):
+    x, w = rnd(M, K, seed=11), rnd(V, K, seed=12, scale=0.02)
+    x_hi, x_lo = ops.split(x.cuda())
+    w_hi, w_lo = ops.split(w.cuda())
+    ids = ops.round_argmax(x_hi, x_lo, w_hi, w_lo, precision).cpu()
+    if precision == "bf16":
+        logits = x_hi.cpu().double() @ w_hi.cpu().double().t()
+    else:
+        logits = x.double() @ w.double().t()
+    want = logits.argmax(-1)
+    top2 = logits.topk(2, dim=-1).values
+    gap = top2[:, 0] - top2[:, 1]
+    clear = gap > 1e-4 * top2[:, 0].abs().clamp_min(1e-3)  # ids must agree wherever the max is not a near-tie
+    assert torch.equal(ids[clear], want[clear]), (ids[clear] != want[clear]).sum().item()
+    picked = logits.gather(1, ids[:, None])[:, 0]
+    assert ((top2[:, 0] - picked).abs() <= 1e-4 * top2[:, 0].abs().clamp_min(1e-3)).all()
+
+
+def test_round_argmax_first_index_wins_ties(ops):
+    M, V, K = 40, 700, 64
+    x, w = rnd(M, K, seed=13), rnd(V, K, seed=14, scale=0.05)
+    w[650] = w[3]
+    w[400] = w[3]
+    x[:] = w[3] * 50  # rows aligned with w[3]: rows 3, 400, 650 of W give bitwise-identical maxima
+    x_hi, x_lo = ops.split(x.cuda())
+    w_hi, w_lo = ops.split(w.cuda())
+    for precision in ("bf16", "bf16x3"):
+        ids = ops.round_argmax(x_hi, x_lo, w_hi, w_lo, precision).cpu()
+        assert (ids == 3).all(), ids
+
+
+def test_first_eos(ops):
+    ids = torch.randint(5, 100, (9, 23), generator=torch.Generator().manual_seed(1))
+    ids[0, 0] = 2
+    ids[1, 22] = 2
+    ids[2, 5] = 2
+    ids[2, 9] = 2
+    lengths = ops.first_eos(ids.cuda(), 2).cpu().tolist()
+    want = [1, 23, 6] + [23] * 6
+    assert lengths == want
+
+
+# ------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, heads, causal, key_mask):
+    B, Sq, HD = q.shape
+    Sk, d = k.shape[1], HD // heads
+    qh = q.double().view(B, Sq, heads, d).transpose(1, 2)
+    kh = k.double().view(B, Sk, heads, d).transpose(1, 2)
+    vh = v.double().view(B, Sk, heads, d).transpose(1, 2)
+    s = qh @ kh.transpose(2, 3) * d**-0.5
+    neg = torch.finfo(torch.float32).min
+    if causal:
+        s = s.masked_fill(~torch.tril(torch.ones(Sq, Sk, dtype=torch.bool)), neg)
+    if key_mask is not None:
+        s = s.masked_fill(key_mask[:, None, None, :] == 0, neg)
+    p = torch.softmax(s, -1)
+    return (p @ vh).transpose(1, 2).reshape(B, Sq, HD)
+
+
+@pytest.mark.parametrize("B,heads,Sq,Sk,d,causal,masked", [
+    (3, 4, 23, 23, 32, True, False), (2, 4, 11, 12, 32, False, True), (2, 12, 64, 64, 64, True, False),
+    (2, 12, 64, 64, 64, False, True), (2, 3, 84, 84, 64, True, False), (2, 3, 83, 84, 64, False, True),
+    (2, 4, 12, 12, 24, False, True), (1, 32, 24, 24, 40, False, True), (2, 2, 1, 1, 64, True, False),
+    (1, 2, 96, 96, 64, True, False),
+])
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_attention(ops, B, heads, Sq, Sk, d, causal, masked, precision):
+    HD = heads * d
+    qkv = rnd(B, max(Sq, Sk), 3 * HD, seed=Sq * 7 + d, scale=1.5)
+    q, k, v = qkv[:, :Sq, :HD], qkv[:, :Sk, HD:2 * HD], qkv[:, :Sk, 2 * HD:]
+    key_mask = None
+    if masked:
+        lens = torch.tensor([Sk, max(1, Sk // 3), 2, 1][:B])
+        key_mask = (torch.arange(Sk)[None] < lens[:, None]).int()
+    x3 = precision == "bf16x3"
+    hi, lo = ops.split(qkv.cuda(), need_lo=x3)
+
+    def view(t, s, c0):
+        return None if t is None else t[:, :s, c0:c0 + HD]
+
+    if Sq == Sk:  # strided views of one fused buffer (ld = 3*HD), as the decoder uses them
+        qp, kp, vp = [(view(hi, Sk, i * HD), view(lo, Sk, i * HD)) for i in range(3)]
+    else:
+        qp = tuple(None if t is None else t[:, :Sq, :HD].contiguous() for t in (hi, lo))
+        kv_hi = hi[:, :Sk, HD:].contiguous()
+        kv_lo = None if lo is None else lo[:, :Sk, HD:].contiguous()
+        kp = (kv_hi[:, :, :HD], None if kv_lo is None else kv_lo[:, :, :HD])
+        vp = (kv_hi[:, :, HD:], None if kv_lo is None else kv_lo[:, :, HD:])
+    o_hi, o_lo = ops.attention(qp, kp, vp, heads, causal=causal, key_mask=None if key_mask is None else key_mask.cuda(),
+                               precision=precision)
+    if x3:
+        want = _attn_ref(q, k, v, heads, causal, key_mask)
+        got, tol = ops.join(o_hi, o_lo), 5e-5
+    else:
+        f = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+        want = _attn_ref(f(q), f(k), f(v), heads, causal, key_mask)
+        got, tol = o_hi.float(), 1.2e-2  # P and O are additionally rounded to bf16
+    assert rel_l2(got, want) <= tol, rel_l2(got, want)
+    assert torch.isfinite(got).all()
+
+
+def test_attention_all_keys_masked_is_uniform(ops):
+    """HF additive-mask semantics: a dialog whose context is fully padded averages V uniformly."""
+    B, heads, S, d = 2, 2, 8, 32
+    qkv = rnd(B, S, 3 * heads * d, seed=3)
+    hi, lo = ops.split(qkv.cuda())
+    HD = heads * d
+    parts = [(hi[:, :, i * HD:(i + 1) * HD], lo[:, :, i * HD:(i + 1) * HD]) for i in range(3)]
+    mask = torch.zeros(B, S, dtype=torch.int32)
+    mask[1, :3] = 1
+    o_hi, o_lo = ops.attention(*parts, heads, causal=False, key_mask=mask.cuda(), precision="bf16x3")
+    got = ops.join(o_hi, o_lo).cpu()
+    v = qkv[:, :, 2 * HD:]
+    assert torch.allclose(got[0], v[0].mean(0, keepdim=True).expand(S, HD), atol=1e-4)
+    assert torch.isfinite(got).all()

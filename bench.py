@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Benchmark of the DiDi sampler hot path on MI355X (contract: see the task's bench.py section).
+
+One "step" = one full `sample()` over one synthetic CommonSense-shaped batch: context encoder +
+adapter, hoisted cross-K/V, T denoiser calls with the fused DDPM update, rounding argmax, eos
+lengths and (N > 1) the RCCL gather of token ids.  Default workload = BASELINE.json configs[1]:
+blenderbot-400M-distill-sized encoder + BertConfig-default decoder, T = 2000, step_freq = 1,
+batch 256 per GPU, context/target 64.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|bf16x3] [--mode ddpm|euler] [--freq F]
+
+Prints ONE JSON line on rank 0: metric/value (sampled dialogs/s, whole job), plus
+  roofline     : the dominant kernel (MFMA GEMM), algorithmic FLOPs / launch duration measured with
+                 HIP events around every GEMM launch of one denoiser call inside the timed region
+  cpu_baseline : the CPU oracle (port of the reference path, fp32 torch eager) timed on a bounded
+                 sample of the same workload on the host cores (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+class GemmProf:
+    """HIP events for the engine's per-GEMM timing hook (didi_forward_args.prof_events_host)."""
+
+    def __init__(self, call, capacity=256):
+        from didi_amd._lib import check, lib  # events are created inside libdidi_hip's HIP runtime
+
+        self.lib, self.check = lib, check
+        self.call, self.capacity, self.used = call, capacity, C.c_int(0)
+        self.events = (C.c_void_p * capacity)()
+        for i in range(capacity):
+            ev = C.c_void_p()
+            check(lib.didi_event_create(C.byref(ev)), "event_create")
+            self.events[i] = ev
+
+    def durations_ms(self):
+        out = []
+        for i in range(0, self.used.value, 2):
+            ms = C.c_float()
+            self.check(self.lib.didi_event_elapsed_ms(self.events[i], self.events[i + 1], C.byref(ms)), "event_elapsed")
+            out.append(ms.value)
+        return out
+
+    def close(self):
+        for ev in self.events:
+            self.lib.didi_event_destroy(ev)
+
+
+def gemm_flops_per_call(cfg, M):
+    """Algorithmic FLOPs (2*M*N*K, NOT x3 for the split-bf16 passes) of the 6 decoder GEMMs x L, launch order."""
+    H, I = cfg.dec_dim, cfg.dec_ffn
+    per_layer = [(3 * H, H), (H, H), (H, H), (H, H), (I, H), (H, I)]
+    return [2.0 * M * n * k for _ in range(cfg.dec_layers) for n, k in per_layer]
+
+
+def cpu_baseline(cfg, sd, ids, mask, S, n_calls_total, budget_calls=3):
+    """Time the CPU oracle on the full batch: encoder once + `budget_calls` denoiser calls + rounding;
+    extrapolate linearly in the number of denoiser calls."""
+    from golden_util import config_to_oracle_config
+    from oracle.model import OracleDiDi
+
+    threads = torch.get_num_threads()
+    oracle = OracleDiDi(sd, config_to_oracle_config(cfg))
+    B = ids.shape[0]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, S, cfg.dec_dim, generator=g)
+    ones = torch.ones(B, 1, dtype=torch.long)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ctx = oracle.encode_context(ids, mask)
+        t_enc = time.perf_counter() - t0
+        oracle(encoder_attention_mask=mask, decoder_inputs_embeds=x, time_ids=ones, context=ctx)  # warm-up call
+        t0 = time.perf_counter()
+        for k in range(budget_calls):
+            x0, _ = oracle(encoder_attention_mask=mask, decoder_inputs_embeds=x, time_ids=(k + 2) * ones, context=ctx)
+            x = x0
+        t_call = (time.perf_counter() - t0) / budget_calls
+        t0 = time.perf_counter()
+        oracle.classifier(x0).argmax(-1)
+        t_round = time.perf_counter() - t0
+    total = t_enc + n_calls_total * t_call + t_round
+    return {
+        "value": B / total, "unit": "dialogs/s", "cores": threads, "kind": "port",
+        "sample": (f"CPU oracle (fp32 torch eager, {threads} threads) on the full batch of {B}: encoder once "
+                   f"({t_enc:.2f}s) + {budget_calls} of {n_calls_total} denoiser calls ({t_call:.2f}s each) + rounding "
+                   f"({t_round:.2f}s); per-batch time extrapolated linearly in the call count = {total:.0f}s"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16", "bf16x3"])
+    ap.add_argument("--mode", default="ddpm", choices=["ddpm", "euler"])
+    ap.add_argument("--freq", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="dialogs per GPU")
+    ap.add_argument("--seq", type=int, default=64, help="context length = target length")
+    ap.add_argument("--diffusion-steps", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from didi_amd import dist as ddist
+    from didi_amd.config import DiDiConfig
+    from didi_amd.model import DiDiSampler
+    from didi_amd.schedule import ddpm_plan
+    from didi_amd.synthetic import RawContext, synthetic_batch, synthetic_state_dict
+
+    rank, world, local_rank = ddist.init_from_env("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = torch.device("cuda", local_rank)
+
+    cfg = DiDiConfig(diffusion_steps=args.diffusion_steps)
+    sd = synthetic_state_dict(cfg, seed=1234)
+    model = DiDiSampler(sd, cfg, device=dev, precision=args.precision)
+    B_total, S = args.batch * world, args.seq
+    ids, mask = synthetic_batch(B_total, args.seq, cfg.vocab, seed=0xBADB01)
+    ctx = RawContext(ids.to(dev), mask.to(dev))  # inputs resident in HBM before the timed region
+    n_calls = ddpm_plan(model._sigmas_host, cfg.diffusion_steps, args.freq).n_calls  # same count for euler
+
+    def step(prof=None):
+        return ddist.sample_sharded(ctx, model, args.mode, args.freq, rank=rank, world=world, max_len=S, eos_id=2, _prof=prof)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    torch.manual_seed(0xBADB01)
+    for _ in range(args.warmup):
+        step()
+    prof = GemmProf(call=n_calls // 2)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out_ids, out_len = step(prof if k == 0 else None)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    assert tuple(out_ids.shape) == (B_total, S) and int(out_len.min()) >= 1
+
+    # roofline of the dominant kernel (MFMA GEMM) from the HIP events of one denoiser call
+    M = args.batch * S
+    dur = prof.durations_ms()
+    flops = gemm_flops_per_call(cfg, M)
+    roofline = None
+    if len(dur) == len(flops):
+        achieved = sum(flops) / (sum(dur) * 1e-3) / 1e12
+        roofline = {
+            "bound": "mfma", "kernel": "gemm_kernel", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "launches": len(dur), "avg_launch_us": round(1e3 * sum(dur) / len(dur), 2),
+            "avg_gflop_per_launch": round(sum(flops) / len(flops) / 1e9, 2),
+            "gemm_share_of_call": round(sum(dur) / (1e3 * elapsed / (args.steps * n_calls)), 3),
+            "note": ("algorithmic FLOPs 2*M*N*K per launch; bf16x3 issues 3 MFMA passes per product, "
+                     "which are not counted" if args.precision == "bf16x3" else "algorithmic FLOPs 2*M*N*K per launch"),
+        }
+    prof.close()
+
+    value = B_total * args.steps / elapsed
+    res = {
+        "metric": "sampled dialogs/sec (whole node, T steps)", "value": round(value, 3), "unit": "dialogs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 1),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {
+            "workload": (f"BASELINE configs[1]: blenderbot-400M-distill-sized encoder (2x1280/32h/5120) + BertConfig-default "
+                         f"decoder (12x768/12h/3072), V={cfg.vocab}, {args.mode} T={cfg.diffusion_steps} step_freq={args.freq} "
+                         f"({n_calls} denoiser calls), batch {args.batch}/GPU, context {args.seq}, target {S}"),
+            "global_batch": B_total, "seq_len": S, "denoiser_calls": n_calls, "parallelism": f"dp{world} (batch shard, id all-gather)",
+            "weights": "random-init N(0,0.02), seed 1234", "noise": "in-kernel Philox",
+        },
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(cfg, sd, ids[: args.batch], mask[: args.batch], S, n_calls)
+        res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
+        res["cpu_baseline"]["value"] = round(res["cpu_baseline"]["value"], 5)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,8 @@ fails to load, importing this module raises: there is no fallback path.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- first: its bundled libamdhip64.so.7 must be the one HIP runtime in the process
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdidi_hip.so")
 
@@ -83,6 +85,7 @@ class ForwardArgs(C.Structure):
         ("kv_hi", C.c_void_p), ("kv_lo", C.c_void_p), ("ctx_mask", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("x0_f32", C.c_void_p), ("x0_hi", C.c_void_p), ("x0_lo", C.c_void_p),
+        ("prof_events_host", C.POINTER(C.c_void_p)), ("prof_capacity", C.c_int), ("prof_used_host", C.POINTER(C.c_int)),
     ]
 
 
@@ -96,6 +99,8 @@ class SampleArgs(C.Structure):
         ("x_state", C.c_void_p), ("x0_f32", C.c_void_p), ("x0_hi", C.c_void_p), ("x0_lo", C.c_void_p),
         ("cls_hi", C.c_void_p), ("cls_lo", C.c_void_p), ("V", C.c_int), ("argmax_partial", C.c_void_p),
         ("ids64", C.c_void_p),
+        ("prof_call", C.c_int), ("prof_events_host", C.POINTER(C.c_void_p)), ("prof_capacity", C.c_int),
+        ("prof_used_host", C.POINTER(C.c_int)),
     ]
 
 
@@ -122,6 +127,9 @@ SYMBOLS = [
                                                C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("didi_decoder_forward", C.c_int, [C.POINTER(Decoder), C.POINTER(ForwardArgs), C.c_void_p]),
     ("didi_sample", C.c_int, [C.POINTER(Decoder), C.POINTER(SampleArgs), C.c_void_p]),
+    ("didi_event_create", C.c_int, [C.POINTER(C.c_void_p)]),
+    ("didi_event_elapsed_ms", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    ("didi_event_destroy", C.c_int, [C.c_void_p]),
 ]
 
 

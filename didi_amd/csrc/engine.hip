@@ -53,8 +53,15 @@ bool shapes_ok(const didi_decoder* d, int B, int S, int C) {
     return true;
 }
 
+struct Prof {
+    void** ev; int cap; int used;
+    void mark(void* stream) {
+        if (ev && used < cap) { (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[used]), as_stream(stream)); ++used; }
+    }
+};
+
 int gemm(const didi_linear& w, int precision, int M, const u16* a_hi, const u16* a_lo, int lda, int act, const u16* r_hi,
-         const u16* r_lo, int ldr, float* c_f32, u16* c_hi, u16* c_lo, int ldc, void* stream) {
+         const u16* r_lo, int ldr, float* c_f32, u16* c_hi, u16* c_lo, int ldc, void* stream, Prof* prof = nullptr) {
     didi_gemm_args g{};
     g.M = M; g.N = w.N; g.K = w.K; g.precision = precision;
     g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
@@ -62,7 +69,10 @@ int gemm(const didi_linear& w, int precision, int M, const u16* a_hi, const u16*
     g.bias = w.bias; g.act = act;
     g.R_hi = r_hi; g.R_lo = r_lo; g.ldr = ldr;
     g.C_f32 = c_f32; g.C_hi = c_hi; g.C_lo = c_lo; g.ldc = ldc;
-    return didi_gemm_bf16(&g, stream);
+    if (prof) prof->mark(stream);
+    const int rc = didi_gemm_bf16(&g, stream);
+    if (prof) prof->mark(stream);
+    return rc;
 }
 
 }  // namespace
@@ -119,6 +129,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
     const int M = a->B * a->S, H = dec->H, I = dec->I, D = H / dec->heads;
     const bool x3 = prec == DIDI_PREC_BF16X3;
     const size_t Mc = (size_t)a->B * a->C;
+    Prof prof{a->prof_events_host, a->prof_capacity, 0};
 
     // sampler step + time embedding + BertEmbeddings
     didi_step_args st = a->step;
@@ -133,7 +144,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         const bool last = l == dec->L - 1;
         // --- causal self-attention block
         TRY(gemm(ly.qkv, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, w.qkv_hi,
-                 x3 ? w.qkv_lo : nullptr, 3 * H, stream));
+                 x3 ? w.qkv_lo : nullptr, 3 * H, stream, &prof));
         didi_attn_args at{};
         at.B = a->B; at.heads = dec->heads; at.Sq = a->S; at.Sk = a->S; at.D = D; at.precision = prec;
         at.causal = 1; at.key_mask = nullptr;
@@ -142,24 +153,24 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.V_hi = w.qkv_hi + 2 * H; at.V_lo = x3 ? w.qkv_lo + 2 * H : nullptr; at.ldv = 3 * H;
         at.O_hi = w.att_hi; at.O_lo = x3 ? w.att_lo : nullptr; at.ldo = H;
         TRY(didi_attention(&at, stream));
-        TRY(gemm(ly.attn_out, prec, M, w.att_hi, w.att_lo, H, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream));
+        TRY(gemm(ly.attn_out, prec, M, w.att_hi, w.att_lo, H, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream, &prof));
         TRY(didi_layernorm(w.tmp, ly.ln1_g, ly.ln1_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, stream));
         // --- cross-attention block (K/V hoisted: didi_decoder_prepare_context)
         u16* q_hi = w.qkv_hi;
         u16* q_lo = x3 ? w.qkv_lo : nullptr;
-        TRY(gemm(ly.cq, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream));
+        TRY(gemm(ly.cq, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream, &prof));
         const size_t kvoff = (size_t)l * Mc * 2 * H;
         at.Sk = a->C; at.causal = 0; at.key_mask = a->ctx_mask;
         at.Q_hi = q_hi; at.Q_lo = q_lo; at.ldq = H;
         at.K_hi = a->kv_hi + kvoff; at.K_lo = x3 ? a->kv_lo + kvoff : nullptr; at.ldk = 2 * H;
         at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;
         TRY(didi_attention(&at, stream));
-        TRY(gemm(ly.cross_out, prec, M, w.att_hi, w.att_lo, H, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream));
+        TRY(gemm(ly.cross_out, prec, M, w.att_hi, w.att_lo, H, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream, &prof));
         TRY(didi_layernorm(w.tmp, ly.ln2_g, ly.ln2_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, stream));
         // --- feed-forward block
         TRY(gemm(ly.ffn_up, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_GELU, nullptr, nullptr, 0, nullptr, w.ffn_hi,
-                 x3 ? w.ffn_lo : nullptr, I, stream));
-        TRY(gemm(ly.ffn_down, prec, M, w.ffn_hi, w.ffn_lo, I, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream));
+                 x3 ? w.ffn_lo : nullptr, I, stream, &prof));
+        TRY(gemm(ly.ffn_down, prec, M, w.ffn_hi, w.ffn_lo, I, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream, &prof));
         if (!last) {
             TRY(didi_layernorm(w.tmp, ly.ln3_g, ly.ln3_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, stream));
         } else {
@@ -168,6 +179,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
             TRY(didi_layernorm(w.tmp, ly.ln3_g, ly.ln3_b, dec->ln_eps, M, H, o_hi, o_lo, a->x0_f32, stream));
         }
     }
+    if (a->prof_used_host) *a->prof_used_host = prof.used;
     return DIDI_OK;
 }
 
@@ -187,6 +199,12 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
     f.workspace = s->workspace; f.workspace_bytes = s->workspace_bytes;
     f.x0_f32 = s->x0_f32;
     auto draw = [&](int i) -> const float* { return s->noise ? s->noise + (size_t)i * MH : nullptr; };
+    auto set_prof = [&](int k) {
+        const bool on = s->prof_events_host && k == s->prof_call;
+        f.prof_events_host = on ? s->prof_events_host : nullptr;
+        f.prof_capacity = on ? s->prof_capacity : 0;
+        f.prof_used_host = on ? s->prof_used_host : nullptr;
+    };
 
     if (!s->euler) {
         for (int k = 0; k < s->n_calls; ++k) {
@@ -199,6 +217,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
             else { st.mode = DIDI_STEP_DDPM; st.X0 = s->x0_f32; st.cx0 = s->c0_host[k - 1]; st.ce = s->c1_host[k - 1]; }
             st.t = s->time_row_host[k];
             st.xin_out = s->xt_trace ? s->xt_trace + (size_t)k * MH : nullptr;
+            set_prof(k);
             const bool last = k == s->n_calls - 1;
             f.x0_hi = last ? s->x0_hi : nullptr;
             f.x0_lo = last ? s->x0_lo : nullptr;
@@ -226,6 +245,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
             st.t = s->time_row_host[k];
             st.xin_out = s->xt_trace ? s->xt_trace + (size_t)k * MH : nullptr;
             f.x0_hi = nullptr; f.x0_lo = nullptr;
+            set_prof(k);
             TRY(didi_decoder_forward(dec, &f, stream));
         }
         // final Euler update lands on sigma = 0 (src/sampling.py:80): x0 <- x + (x - x0_hat) * ratio
@@ -241,4 +261,24 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
                               s->precision, s->argmax_partial, s->ids64, nullptr, stream));
     }
     return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ timing helpers for bench.py
+// hipEvent wrappers so that the benchmark creates its events in the SAME HIP runtime instance this
+// library is bound to (a ctypes-loaded second copy of libamdhip64 would not share streams).
+extern "C" int didi_event_create(void** ev) {
+    DIDI_CHECK_ARG(ev);
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return DIDI_ERR_LAUNCH;
+    *ev = e;
+    return DIDI_OK;
+}
+extern "C" int didi_event_elapsed_ms(void* start, void* stop, float* ms) {
+    DIDI_CHECK_ARG(start && stop && ms);
+    return hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)) == hipSuccess
+               ? DIDI_OK : DIDI_ERR_LAUNCH;
+}
+extern "C" int didi_event_destroy(void* ev) {
+    DIDI_CHECK_ARG(ev);
+    return hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)) == hipSuccess ? DIDI_OK : DIDI_ERR_LAUNCH;
 }

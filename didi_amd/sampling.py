@@ -24,6 +24,7 @@ Extra keyword-only arguments (all optional; defaults reproduce the reference cal
           tensor    injected stream [n_draws, B, S, H] in the reference's draw order (parity tests)
   trace   list      receives the denoiser input x_t of every call (fp32 [B,S,H], on device)
   return_ids        return (ids [B,S] int64, lengths [B] int32) instead of decoded strings
+  philox_offset     first Philox counter of this call (didi_amd/dist.py gives every rank a disjoint range)
 """
 import ctypes as C
 
@@ -55,7 +56,7 @@ def _host_arrays(plan, mode):
 
 @torch.no_grad()
 def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, max_len=-1, raw_output=False,
-           skip_special=True, *, noise=None, trace=None, return_ids=False):
+           skip_special=True, *, noise=None, trace=None, return_ids=False, philox_offset=0, _prof=None):
     if mode not in ("ddpm", "euler"):
         raise NotImplementedError(f"No {mode} sampling strategy")
     if not raw_output and not return_ids and tokenizer is None:
@@ -82,7 +83,7 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
     b = model.prepare_context(context, attention_mask, S)
 
     MH = B * S * H
-    seed = base_offset = 0
+    seed, base_offset = 0, int(philox_offset)
     noise_t = None
     if noise is None:
         # one draw from the global generator -> Philox key: reproducible under torch.manual_seed
@@ -120,6 +121,9 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
         if want_ids:
             a.cls_hi, a.cls_lo, a.V = model._cls.hi.data_ptr(), model._cls.lo.data_ptr(), V
             a.argmax_partial, a.ids64 = b["partial"].data_ptr(), ids.data_ptr()
+        if _prof is not None:  # bench.py: HIP events around the GEMM launches of one denoiser call
+            a.prof_call, a.prof_events_host, a.prof_capacity = _prof.call, _prof.events, _prof.capacity
+            a.prof_used_host = C.pointer(_prof.used)
         _lib.check(lib.didi_sample(C.byref(model._dec), C.byref(a), _lib.current_stream()), "sample")
         if trace is not None:
             trace.extend(xt_trace.unbind(0))

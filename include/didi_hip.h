@@ -256,6 +256,13 @@ typedef struct didi_forward_args {
     size_t workspace_bytes;
     float* x0_f32;
     uint16_t *x0_hi, *x0_lo;
+    /* optional per-launch timing of the GEMM kernel (bench.py's roofline leg): when prof_events !=
+     * NULL, a hipEvent_t from this HOST array is recorded on `stream` before and after every GEMM
+     * launch of this call (2 per launch, in launch order) and *prof_used_host is set to the number
+     * recorded.  The caller creates/destroys the events and reads them after synchronising. */
+    void** prof_events_host;
+    int prof_capacity;
+    int* prof_used_host;
 } didi_forward_args;
 int didi_decoder_forward(const didi_decoder* dec, const didi_forward_args* a, void* stream);
 
@@ -295,8 +302,20 @@ typedef struct didi_sample_args {
     int V;
     void* argmax_partial;
     int64_t* ids64;
+    /* optional: instrument denoiser call number prof_call as in didi_forward_args */
+    int prof_call;
+    void** prof_events_host;
+    int prof_capacity;
+    int* prof_used_host;
 } didi_sample_args;
 int didi_sample(const didi_decoder* dec, const didi_sample_args* a, void* stream);
+
+/* hipEvent wrappers for the prof_events_host hook (bench.py): events must live in the HIP runtime
+ * instance this library is bound to.  Host-side helpers, no reference counterpart.  Elapsed time
+ * may only be read after the caller has synchronised the stream. */
+int didi_event_create(void** ev);
+int didi_event_elapsed_ms(void* start, void* stop, float* ms);
+int didi_event_destroy(void* ev);
 
 #ifdef __cplusplus
 }

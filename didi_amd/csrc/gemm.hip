@@ -1,38 +1,49 @@
 // MFMA bf16 GEMM for the decoder's Linear layers and the rounding (classifier + argmax) step.
 //
-//   C[M,N] = epilogue( sum over passes p of A_p[M,K] * W_p[N,K]^T )      fp32 accumulate
+//   C[M,N] = epilogue( A[M,K] * W[N,K]^T )      fp32 accumulate, operands as bf16 split planes
 //
-// Tile: 128(M) x 128(N) x 64(K) per 256-thread workgroup; 4 waves as 2(M) x 2(N), each wave a
-// 64x64 sub-tile = 4x4 v_mfma_f32_16x16x32_bf16 accumulators.  The MFMA is issued "swapped"
+// Tile: 128(M) x 128(N) per 256-thread workgroup; 4 waves as 2(M) x 2(N), each wave a 64x64
+// sub-tile = 4x4 v_mfma_f32_16x16x32_bf16 accumulators.  The MFMA is issued "swapped"
 // (A-operand = weight rows, B-operand = activation rows) so that every lane ends up holding FOUR
 // CONSECUTIVE OUTPUT COLUMNS n of one output row m: the epilogue then loads bias as one float4 and
 // stores 8-byte bf16 packs / 16-byte fp32 vectors instead of scalars.
 //
-// LDS image (same for both operands): [128 rows][64 bf16] = 128-byte rows, 16-byte chunk c of row
-// r stored at chunk position c ^ (r & 7).  With that XOR the 16-lane groups in which the hardware
-// services ds_read_b128 hit 16 distinct 16-byte slots of the 256-byte bank row: conflict-free
-// fragment reads (cdna_hip_programming.md T2).  Two LDS stages (64 KiB), register prefetch of the
-// next K-tile issued before the current tile's MFMAs, one barrier per K-tile.
-//
-// "bf16x3": the three products hi*hi, hi*lo, lo*hi are three extra trips of the SAME K loop over
-// different plane pointers into the same accumulators -- the kernel sees a GEMM with K' = 3K.
+// Main loop (tile_glds): operand tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no
+// staging registers, no ds_write -- the register-staged first version of this kernel was bound by
+// ds_write_b128 issue, profiles/r01_v1_*), two LDS stages of 32 KiB, the DMA of K-tile t+1 in
+// flight while K-tile t is multiplied, one barrier per K-tile.
+//   precision bf16   : K-tile 64;  stage = {A_hi, W_hi} tiles of [128 rows][128 B]
+//   precision bf16x3 : K-tile 32;  stage = {A_hi, A_lo, W_hi, W_lo} tiles of [128 rows][64 B]; the
+//                      three products lo*hi, hi*lo, hi*hi are issued from ONE staging of the four
+//                      tiles (48 MFMAs per 16 fragment reads) instead of three trips over K.
+// LDS image: an LDS-DMA instruction writes 1 KiB = lane-linear 16-byte slots, so the bank-conflict
+// swizzle is applied to the per-lane SOURCE address and again on the fragment read
+// (cdna_hip_programming.md rule 21): slot s of row r holds k-chunk s ^ f(r), with
+// f(r) = r & 7 for 128-byte rows and f(r) = (-(r >> 2)) & 3 for 64-byte rows; both make every
+// 16-lane ds_read_b128 group hit 16 distinct 16-byte slots of the 256-byte bank row.
+// tile_regstage is the generic fallback (K not a multiple of the K-tile): register staging with
+// zero-fill past K, three passes over K for bf16x3.
 //
 // Grid: 1-D, XCD-aware: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs,
 // so id -> (id % 8) * chunk + id / 8 gives each XCD (private 4 MiB L2) a contiguous band of output
 // row-tiles: a band's activation rows are fetched from HBM once per XCD while the small weight
 // matrix (<= 4.7 MB) stays L2-resident.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 #define BM 128
 #define BN 128
-#define BK 64
-#define TILE_BYTES (128 * 128)  // one operand tile in LDS
+#define STAGE_BYTES 32768
+#define SMEM_BYTES (2 * STAGE_BYTES)
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
 
 struct GemmParams {
     int M, N, K;
     int npass;
-    const u16* A[3];
-    const u16* W[3];
+    const u16 *A_hi, *A_lo, *W_hi, *W_lo;
     int lda, ldw;
     const float* bias;
     int act;
@@ -47,10 +58,127 @@ struct GemmParams {
     float2* partial;  // [M][nchunks] (value, index bits)
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+__device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+__device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4); }
 
-// Accumulate one 128x128 output tile at (m0, n0) into acc.  All 256 threads participate.
-__device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m0, int n0, f32x4 (&acc)[4][4]) {
+__device__ __forceinline__ void glds16(const u16* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)lds_dst, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------ LDS-DMA main loop
+// Accumulate one 128x128 output tile at (m0, n0).  Requires K % (NPASS == 3 ? 32 : 64) == 0.
+template <int NPASS, int NSTAGE>
+__device__ __forceinline__ void tile_glds(const GemmParams& p, char* smem, int m0, int n0, f32x4 (&acc)[4][4]) {
+    constexpr int BKK = NPASS == 3 ? 32 : 64;
+    constexpr int ROWB = BKK * 2;              // bytes per LDS row
+    constexpr int TILEB = 128 * ROWB;          // one operand tile
+    constexpr int CPR = ROWB / 16;             // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;              // rows covered by one wave-instruction (1 KiB)
+    constexpr int IPW = 128 / RPI / 4;         // DMA instructions per tile per wave
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane DMA source offsets (elements): instruction j of this wave fills LDS rows
+    // (wave*IPW + j)*RPI ... ; lane -> row = base + lane / CPR, slot = lane % CPR, k-chunk = slot ^ f(row)
+    size_t a_src[IPW], w_src[IPW];
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+        const int row = (wave * IPW + j) * RPI + lane / CPR;
+        const int slot = lane % CPR;
+        const int g = NPASS == 3 ? (slot ^ ((0 - (row >> 2)) & 3)) : (slot ^ (row & 7));
+        a_src[j] = (size_t)min(m0 + row, p.M - 1) * p.lda + g * 8;
+        w_src[j] = (size_t)min(n0 + row, p.N - 1) * p.ldw + g * 8;
+    }
+    const int nt = p.K / BKK;
+
+    auto issue = [&](int t, int buf) {
+        char* st = smem + buf * STAGE_BYTES + wave * IPW * 1024;  // wave-uniform; the DMA adds lane*16
+        const int k0 = t * BKK;
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+            if constexpr (NPASS == 3) {
+                glds16(p.A_hi + k0 + a_src[j], st + 0 * TILEB + j * 1024);
+                glds16(p.A_lo + k0 + a_src[j], st + 1 * TILEB + j * 1024);
+                glds16(p.W_hi + k0 + w_src[j], st + 2 * TILEB + j * 1024);
+                glds16(p.W_lo + k0 + w_src[j], st + 3 * TILEB + j * 1024);
+            } else {
+                glds16(p.A_hi + k0 + a_src[j], st + 0 * TILEB + j * 1024);
+                glds16(p.W_hi + k0 + w_src[j], st + 1 * TILEB + j * 1024);
+            }
+        }
+    };
+
+    // NSTAGE-deep ring: K-tiles t+1 .. t+NSTAGE-2 stay in flight across the barrier (counted vmcnt,
+    // raw s_barrier: __syncthreads() would drain the DMA queue, cdna_hip_programming.md section 5)
+    constexpr int G = IPW * (NPASS == 3 ? 4 : 2);  // DMA instructions per stage per wave
+    static_assert(G == 8, "vmcnt immediates below assume 8 DMA instructions per stage");
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nt) issue(s, s);
+    int buf = 0, nbuf = NSTAGE - 1;
+    for (int t = 0; t < nt; ++t) {
+        // this wave's share of K-tile t has landed once at most the younger stages remain outstanding
+        const int ahead = min(NSTAGE - 2, nt - 1 - t);
+        if (ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone's share has landed; ring slot of K-tile t-1 is free
+        if (t + NSTAGE - 1 < nt) issue(t + NSTAGE - 1, nbuf);
+        const char* st = smem + buf * STAGE_BYTES;
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NSTAGE ? 0 : nbuf + 1;
+        if constexpr (NPASS == 3) {
+            const char *Ah = st, *Al = st + TILEB, *Wh = st + 2 * TILEB, *Wl = st + 3 * TILEB;
+            bf16x8 whf[4], wlf[4], ahf[4], alf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int wo = swz64(wn * 64 + i * 16 + lr, lg);
+                const int ao = swz64(wm * 64 + i * 16 + lr, lg);
+                whf[i] = *reinterpret_cast<const bf16x8*>(Wh + wo);
+                wlf[i] = *reinterpret_cast<const bf16x8*>(Wl + wo);
+                ahf[i] = *reinterpret_cast<const bf16x8*>(Ah + ao);
+                alf[i] = *reinterpret_cast<const bf16x8*>(Al + ao);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlf[ni], ahf[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whf[ni], alf[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whf[ni], ahf[mi], acc[ni][mi], 0, 0, 0);
+                }
+        } else {
+            const char *As = st, *Ws = st + TILEB;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 wf[4], af[4];
+                const int chunk = ks * 4 + lg;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wf[i] = *reinterpret_cast<const bf16x8*>(Ws + swz128(wn * 64 + i * 16 + lr, chunk));
+                    af[i] = *reinterpret_cast<const bf16x8*>(As + swz128(wm * 64 + i * 16 + lr, chunk));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();  // the staging buffers may be reused right away (argmax variant: next tile)
+}
+
+// ------------------------------------------------------------------ register-staged fallback (any K % 8 == 0)
+__device__ __forceinline__ void tile_regstage(const GemmParams& p, char* smem, int m0, int n0, f32x4 (&acc)[4][4]) {
+    constexpr int BK = 64, TILE_BYTES = 128 * 128;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -65,7 +193,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     // clamped to the last valid row (their products land in accumulators that are never stored)
 #define GEMM_STAGE(I)                                                        \
     const int c##I = tid + 256 * I;                                          \
-    const int so##I = swz(c##I >> 3, c##I & 7);                              \
+    const int so##I = swz128(c##I >> 3, c##I & 7);                           \
     const size_t a_off##I = (size_t)min(m0 + (c##I >> 3), p.M - 1) * p.lda + (c##I & 7) * 8; \
     const size_t w_off##I = (size_t)min(n0 + (c##I >> 3), p.N - 1) * p.ldw + (c##I & 7) * 8;
     GEMM_STAGE(0) GEMM_STAGE(1) GEMM_STAGE(2) GEMM_STAGE(3)
@@ -74,12 +202,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     const int nt = kt_per_pass * p.npass;
 
     // (no lambdas / runtime-indexed arrays here: either leaves the prefetch registers in scratch)
+    // passes: lo*hi, hi*lo, then the dominant hi*hi
 #define GEMM_GLOAD(T)                                                                   \
     {                                                                                   \
-        const int pass_ = (T) / kt_per_pass;                                            \
-        const int k0_ = ((T) - pass_ * kt_per_pass) * BK;                               \
-        const u16* Ab_ = (pass_ == 0 ? p.A[0] : pass_ == 1 ? p.A[1] : p.A[2]) + k0_;    \
-        const u16* Wb_ = (pass_ == 0 ? p.W[0] : pass_ == 1 ? p.W[1] : p.W[2]) + k0_;    \
+        const int pass_ = p.npass == 1 ? 2 : (T) / kt_per_pass;                         \
+        const int k0_ = ((T) % kt_per_pass) * BK;                                       \
+        const u16* Ab_ = (pass_ == 0 ? p.A_lo : p.A_hi) + k0_;                          \
+        const u16* Wb_ = (pass_ == 1 ? p.W_lo : p.W_hi) + k0_;                          \
         const uint4 z_ = make_uint4(0, 0, 0, 0);                                        \
         const bool in0_ = k0_ + (c0 & 7) * 8 < p.K, in1_ = k0_ + (c1 & 7) * 8 < p.K;    \
         const bool in2_ = k0_ + (c2 & 7) * 8 < p.K, in3_ = k0_ + (c3 & 7) * 8 < p.K;    \
@@ -117,10 +246,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
             const int chunk = ks * 4 + lg;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int nl = wn * 64 + i * 16 + lr;
-                const int ml = wm * 64 + i * 16 + lr;
-                wf[i] = *reinterpret_cast<const bf16x8*>(Ws + swz(nl, chunk));
-                af[i] = *reinterpret_cast<const bf16x8*>(As + swz(ml, chunk));
+                wf[i] = *reinterpret_cast<const bf16x8*>(Ws + swz128(wn * 64 + i * 16 + lr, chunk));
+                af[i] = *reinterpret_cast<const bf16x8*>(As + swz128(wm * 64 + i * 16 + lr, chunk));
             }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
@@ -135,10 +262,62 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
 #undef GEMM_LSTORE
 }
 
+// MODE 0: register-staged fallback, 1: LDS-DMA bf16, 3: LDS-DMA bf16x3
+template <int MODE, int NSTAGE>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m0, int n0, f32x4 (&acc)[4][4]) {
+    if constexpr (MODE == 0) tile_regstage(p, smem, m0, n0, acc);
+    else tile_glds<MODE, NSTAGE>(p, smem, m0, n0, acc);
+}
+
+// erf to <= 1.5e-7 absolute (Abramowitz & Stegun 7.1.26): rcp + exp + 5 fma instead of libm's
+// ~40-instruction erff, which cost the FFN-up epilogue ~40 us per launch (profiles/r01 notes).
+// GELU(x) = 0.5 x (1 + erf(x/sqrt2)) then carries <= 1.5e-7 relative error: far inside the
+// bf16x3 budget (1e-5) and invisible next to the bf16 split rounding of the stored value.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.0f - poly * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == DIDI_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == DIDI_ACT_GELU) return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f));
     if (act == DIDI_ACT_TANH) return tanhf(v);
     return v;
+}
+
+// epilogue for 4 consecutive output columns n..n+3 of row m: bias, activation, residual, stores
+__device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, float v0, float v1, float v2, float v3) {
+    if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+    }
+    if (p.act != DIDI_ACT_NONE) {
+        v0 = act_apply(v0, p.act); v1 = act_apply(v1, p.act); v2 = act_apply(v2, p.act); v3 = act_apply(v3, p.act);
+    }
+    if (p.R_f32) {
+        const float4 r = *reinterpret_cast<const float4*>(p.R_f32 + (size_t)m * p.ldr + n);
+        v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+    } else if (p.R_hi) {
+        const uint2 rh = *reinterpret_cast<const uint2*>(p.R_hi + (size_t)m * p.ldr + n);
+        v0 += bf16_to_f32((u16)(rh.x & 0xffff)); v1 += bf16_to_f32((u16)(rh.x >> 16));
+        v2 += bf16_to_f32((u16)(rh.y & 0xffff)); v3 += bf16_to_f32((u16)(rh.y >> 16));
+        if (p.R_lo) {
+            const uint2 rl = *reinterpret_cast<const uint2*>(p.R_lo + (size_t)m * p.ldr + n);
+            v0 += bf16_to_f32((u16)(rl.x & 0xffff)); v1 += bf16_to_f32((u16)(rl.x >> 16));
+            v2 += bf16_to_f32((u16)(rl.y & 0xffff)); v3 += bf16_to_f32((u16)(rl.y >> 16));
+        }
+    }
+    const size_t o = (size_t)m * p.ldc + n;
+    if (p.C_f32) *reinterpret_cast<float4*>(p.C_f32 + o) = make_float4(v0, v1, v2, v3);
+    if (p.C_hi) {
+        const float v[4] = {v0, v1, v2, v3};
+        uint2 h, l;
+        split4(v, h, l);
+        *reinterpret_cast<uint2*>(p.C_hi + o) = h;
+        if (p.C_lo) *reinterpret_cast<uint2*>(p.C_lo + o) = l;
+    }
 }
 
 // bijective XCD remap of a 1-D grid (cdna_hip_programming.md, "XCD swizzle must be bijective")
@@ -147,12 +326,13 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
 }
 
-__global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
+template <int MODE, int NSTAGE>
+__global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     f32x4 acc[4][4];
-    gemm_tile(p, smem, m0, n0, acc);
+    gemm_tile<MODE, NSTAGE>(p, smem, m0, n0, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lg = lane >> 4;
@@ -164,56 +344,170 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
         for (int ni = 0; ni < 4; ++ni) {
             const int n = n0 + wn * 64 + ni * 16 + lg * 4;
             if (n >= p.N) continue;
-            float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
-            if (p.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (p.act != DIDI_ACT_NONE) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
-            }
-            if (p.R_f32) {
-                const float4 r = *reinterpret_cast<const float4*>(p.R_f32 + (size_t)m * p.ldr + n);
-                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-            } else if (p.R_hi) {
-                float rh[4], rl[4] = {0.f, 0.f, 0.f, 0.f};
-                unpack4(*reinterpret_cast<const uint2*>(p.R_hi + (size_t)m * p.ldr + n), rh);
-                if (p.R_lo) unpack4(*reinterpret_cast<const uint2*>(p.R_lo + (size_t)m * p.ldr + n), rl);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += rh[e] + rl[e];
-            }
-            const size_t o = (size_t)m * p.ldc + n;
-            if (p.C_f32) *reinterpret_cast<float4*>(p.C_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
-            if (p.C_hi) {
-                uint2 h, l;
-                split4(v, h, l);
-                *reinterpret_cast<uint2*>(p.C_hi + o) = h;
-                if (p.C_lo) *reinterpret_cast<uint2*>(p.C_lo + o) = l;
-            }
+            epilogue4(p, m, n, acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
         }
     }
 }
 
-static int fill_passes(GemmParams& p, int precision, const u16* A_hi, const u16* A_lo, const u16* W_hi, const u16* W_lo) {
+// ------------------------------------------------------------------ big tile: 256(M) x 192(N), 8 waves
+// The 128x128 tile at two workgroups per CU asks the XCD's L2 for 32 KiB per 512 (bf16) / 768
+// (bf16x3) MFMA cycles and workgroup = 42-64 B/clk/CU at full MFMA rate, which is the L2's whole
+// rate (MI355X_MICROARCH.md: ~34.5 TB/s = 56 B/clk/CU): the small tile is L2-bound.  This tile
+// halves the bytes per FLOP (56 KiB per 1536 / 2304 MFMA cycles per SIMD = 36 / 24 B/clk/CU) and
+// its 192 columns divide the decoder's widths exactly (768 = 4, 2304 = 12, 3072 = 16 tiles): with
+// M = 16384 rows the grids are 256 / 768 / 1024 workgroups = 1 / 3 / 4 full rounds of the 256 CUs.
+// 8 waves as 4(M) x 2(N), wave tile 64 x 96 = 4 x 6 MFMA accumulators; one stage = 56 one-KiB
+// LDS-DMA pieces, wave w issues pieces w, w+8, ..., w+48; two stages = 112 KiB, one workgroup per CU.
+#define BBM 256
+#define BBN 192
+#define BIG_STAGE_BYTES 57344
+template <int NPASS>
+__global__ void __launch_bounds__(512, 2) gemm_big_kernel(GemmParams p) {
+    constexpr int BKK = NPASS == 3 ? 32 : 64;
+    constexpr int ROWB = BKK * 2, CPR = ROWB / 16, RPI = 64 / CPR;
+    constexpr int W_OFF = 32768;                        // W tile(s) start (A region = 32 KiB for both precisions)
+    constexpr int LO_A = 16384, LO_W = 12288;           // bf16x3: offset of the lo tile after its hi tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / p.tiles_n) * BBM, n0 = (tile % p.tiles_n) * BBN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    f32x4 acc[6][4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // DMA piece q = wave + 8j (1 KiB at stage offset q*1024): which operand plane, which rows
+    const u16* src[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int q = wave + 8 * j;
+        const u16* base;
+        int row, ld, lim, r0;
+        if (NPASS == 3) {
+            if (q < 16) { base = p.A_hi; row = q * RPI; }
+            else if (q < 32) { base = p.A_lo; row = (q - 16) * RPI; }
+            else if (q < 44) { base = p.W_hi; row = (q - 32) * RPI; }
+            else { base = p.W_lo; row = (q - 44) * RPI; }
+        } else {
+            if (q < 32) { base = p.A_hi; row = q * RPI; }
+            else { base = p.W_hi; row = (q - 32) * RPI; }
+        }
+        if (q < 32) { ld = p.lda; lim = p.M - 1; r0 = m0; } else { ld = p.ldw; lim = p.N - 1; r0 = n0; }
+        row += lane / CPR;
+        const int slot = lane % CPR;
+        const int g = NPASS == 3 ? (slot ^ ((0 - (row >> 2)) & 3)) : (slot ^ (row & 7));
+        src[j] = base + (size_t)min(r0 + row, lim) * ld + g * 8;
+    }
+    const int nt = p.K / BKK;
+    auto issue = [&](int t, int buf) {
+        char* st = smem + buf * BIG_STAGE_BYTES + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) glds16(src[j] + t * BKK, st + j * 8192);
+    };
+
+    issue(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < nt) issue(t + 1, buf ^ 1);
+        const char* st = smem + buf * BIG_STAGE_BYTES;
+        if constexpr (NPASS == 3) {
+            const char *Ah = st, *Al = st + LO_A, *Wh = st + W_OFF, *Wl = st + W_OFF + LO_W;
+            bf16x8 whf[6], wlf[6], ahf[4], alf[4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int wo = swz64(wn * 96 + i * 16 + lr, lg);
+                whf[i] = *reinterpret_cast<const bf16x8*>(Wh + wo);
+                wlf[i] = *reinterpret_cast<const bf16x8*>(Wl + wo);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ao = swz64(wm * 64 + i * 16 + lr, lg);
+                ahf[i] = *reinterpret_cast<const bf16x8*>(Ah + ao);
+                alf[i] = *reinterpret_cast<const bf16x8*>(Al + ao);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 6; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlf[ni], ahf[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whf[ni], alf[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whf[ni], ahf[mi], acc[ni][mi], 0, 0, 0);
+                }
+        } else {
+            const char *As = st, *Ws = st + W_OFF;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 wf[6], af[4];
+                const int chunk = ks * 4 + lg;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(Ws + swz128(wn * 96 + i * 16 + lr, chunk));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + swz128(wm * 64 + i * 16 + lr, chunk));
+#pragma unroll
+                for (int ni = 0; ni < 6; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + lr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 6; ++ni) {
+            const int n = n0 + wn * 96 + ni * 16 + lg * 4;
+            if (n >= p.N) continue;
+            epilogue4(p, m, n, acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+        }
+    }
+}
+
+static int fill_operands(GemmParams& p, int precision, const u16* A_hi, const u16* A_lo, const u16* W_hi, const u16* W_lo) {
+    p.A_hi = A_hi; p.W_hi = W_hi;
     if (precision == DIDI_PREC_BF16) {
         p.npass = 1;
-        p.A[0] = A_hi; p.W[0] = W_hi;
-        p.A[1] = p.A[2] = A_hi; p.W[1] = p.W[2] = W_hi;
+        p.A_lo = A_hi; p.W_lo = W_hi;  // never read
         return DIDI_OK;
     }
     if (precision == DIDI_PREC_BF16X3) {
         if (!A_lo || !W_lo) return DIDI_ERR_BAD_ARG;
-        p.npass = 3;  // small cross terms first, the dominant hi*hi product last
-        p.A[0] = A_lo; p.W[0] = W_hi;
-        p.A[1] = A_hi; p.W[1] = W_lo;
-        p.A[2] = A_hi; p.W[2] = W_hi;
+        p.npass = 3;
+        p.A_lo = A_lo; p.W_lo = W_lo;
         return DIDI_OK;
     }
     return DIDI_ERR_BAD_ARG;
 }
 
+// 0 = register-staged fallback, else the LDS-DMA variant for the precision
+static int pick_mode(const GemmParams& p) {
+    if (p.npass == 3) return p.K % 32 == 0 ? 3 : 0;
+    return p.K % 64 == 0 ? 1 : 0;
+}
+
+// experiment knob (tools/gemm_bench.py): DIDI_GEMM_BIG=0 forces the 128x128 tile everywhere
+static bool gemm_big_enabled() {
+    static const bool v = [] { const char* e = getenv("DIDI_GEMM_BIG"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
+static bool allow_big_lds() {  // > 64 KiB of dynamic LDS needs an opt-in, once per process
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<3>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BIG_STAGE_BYTES) == hipSuccess &&
+                           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BIG_STAGE_BYTES) == hipSuccess;
+    return ok;
+}
+
 static inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+static inline bool al8(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; }
 
 extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
     DIDI_CHECK_ARG(a && a->A_hi && a->W_hi && a->M >= 0 && a->N > 0 && a->K > 0);
@@ -222,22 +516,36 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
     if (a->K % 8 != 0 || a->N % 4 != 0) return DIDI_ERR_UNSUPPORTED;
     DIDI_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldc % 4 == 0 && a->lda >= a->K && a->ldw >= a->K && a->ldc >= a->N);
     DIDI_CHECK_ARG(al16(a->A_hi) && al16(a->A_lo) && al16(a->W_hi) && al16(a->W_lo) && al16(a->bias) && al16(a->R_f32));
-    DIDI_CHECK_ARG((reinterpret_cast<uintptr_t>(a->R_hi) & 7) == 0 && (reinterpret_cast<uintptr_t>(a->R_lo) & 7) == 0);
-    DIDI_CHECK_ARG(al16(a->C_f32) && (reinterpret_cast<uintptr_t>(a->C_hi) & 7) == 0 && (reinterpret_cast<uintptr_t>(a->C_lo) & 7) == 0);
+    DIDI_CHECK_ARG(al8(a->R_hi) && al8(a->R_lo) && al16(a->C_f32) && al8(a->C_hi) && al8(a->C_lo));
     if (a->R_f32 || a->R_hi) DIDI_CHECK_ARG(a->ldr % 4 == 0 && a->ldr >= a->N);
     DIDI_CHECK_ARG(a->act >= DIDI_ACT_NONE && a->act <= DIDI_ACT_TANH);
     if (a->M == 0) return DIDI_OK;
     GemmParams p{};
     p.M = a->M; p.N = a->N; p.K = a->K;
-    int rc = fill_passes(p, a->precision, a->A_hi, a->A_lo, a->W_hi, a->W_lo);
+    int rc = fill_operands(p, a->precision, a->A_hi, a->A_lo, a->W_hi, a->W_lo);
     if (rc != DIDI_OK) return rc;
     p.lda = a->lda; p.ldw = a->ldw;
     p.bias = a->bias; p.act = a->act;
     p.R_f32 = a->R_f32; p.R_hi = a->R_hi; p.R_lo = a->R_lo; p.ldr = a->ldr;
     p.C_f32 = a->C_f32; p.C_hi = a->C_hi; p.C_lo = a->C_lo; p.ldc = a->ldc;
-    p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
-    const int grid = p.tiles_m * p.tiles_n;
-    gemm_kernel<<<grid, 256, 4 * TILE_BYTES, as_stream(stream)>>>(p);
+    hipStream_t st = as_stream(stream);
+    const int mode = pick_mode(p);
+    const int big_tiles_n = cdiv(a->N, BBN);
+    const bool big = mode != 0 && gemm_big_enabled() && a->M >= 2048 && a->N >= BBN &&
+                     (long)big_tiles_n * BBN * 100 <= (long)a->N * 115;  // <= 15 % padded columns
+    if (big) {
+        if (!allow_big_lds()) return DIDI_ERR_LAUNCH;
+        p.tiles_m = cdiv(a->M, BBM); p.tiles_n = big_tiles_n;
+        const int grid = p.tiles_m * p.tiles_n;
+        if (mode == 3) gemm_big_kernel<3><<<grid, 512, 2 * BIG_STAGE_BYTES, st>>>(p);
+        else gemm_big_kernel<1><<<grid, 512, 2 * BIG_STAGE_BYTES, st>>>(p);
+    } else {
+        p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
+        const int grid = p.tiles_m * p.tiles_n;
+        if (mode == 3) gemm_kernel<3, 2><<<grid, 256, SMEM_BYTES, st>>>(p);
+        else if (mode == 1) gemm_kernel<1, 2><<<grid, 256, SMEM_BYTES, st>>>(p);
+        else gemm_kernel<0, 2><<<grid, 256, SMEM_BYTES, st>>>(p);
+    }
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }
@@ -247,7 +555,8 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
 // (max, index) and never writes logits.  Cross-lane / cross-wave reduction once per workgroup.
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
-__global__ void __launch_bounds__(256, 2) gemm_argmax_kernel(GemmParams p) {
+template <int MODE, int NSTAGE>
+__global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_argmax_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int mt = blockIdx.x % p.tiles_m, chunk = blockIdx.x / p.tiles_m;
     const int m0 = mt * BM;
@@ -262,7 +571,7 @@ __global__ void __launch_bounds__(256, 2) gemm_argmax_kernel(GemmParams p) {
     for (int tn = t_begin; tn < t_end; ++tn) {
         const int n0 = tn * BN;
         f32x4 acc[4][4];
-        gemm_tile(p, smem, m0, n0, acc);
+        gemm_tile<MODE, NSTAGE>(p, smem, m0, n0, acc);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -331,11 +640,11 @@ extern "C" int didi_round_argmax(const uint16_t* X_hi, const uint16_t* X_lo, int
     DIDI_CHECK_ARG(X_hi && W_hi && partial && (ids64 || ids32) && M >= 0 && V > 0 && K > 0);
     if (K % 8 != 0) return DIDI_ERR_UNSUPPORTED;
     DIDI_CHECK_ARG(ldx % 8 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K);
-    DIDI_CHECK_ARG(al16(X_hi) && al16(X_lo) && al16(W_hi) && al16(W_lo) && (reinterpret_cast<uintptr_t>(partial) & 7) == 0);
+    DIDI_CHECK_ARG(al16(X_hi) && al16(X_lo) && al16(W_hi) && al16(W_lo) && al8(partial));
     if (M == 0) return DIDI_OK;
     GemmParams p{};
     p.M = M; p.N = V; p.K = K;
-    int rc = fill_passes(p, precision, X_hi, X_lo, W_hi, W_lo);
+    int rc = fill_operands(p, precision, X_hi, X_lo, W_hi, W_lo);
     if (rc != DIDI_OK) return rc;
     p.lda = ldx; p.ldw = ldw;
     p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(V, BN);
@@ -346,7 +655,12 @@ extern "C" int didi_round_argmax(const uint16_t* X_hi, const uint16_t* X_lo, int
     p.nchunks = cdiv(p.tiles_n, p.tiles_per_chunk);
     p.partial = reinterpret_cast<float2*>(partial);
     hipStream_t st = as_stream(stream);
-    gemm_argmax_kernel<<<p.tiles_m * p.nchunks, 256, 4 * TILE_BYTES, st>>>(p);
+    const int grid = p.tiles_m * p.nchunks;
+    switch (pick_mode(p)) {
+        case 3: gemm_argmax_kernel<3, 2><<<grid, 256, SMEM_BYTES, st>>>(p); break;
+        case 1: gemm_argmax_kernel<1, 2><<<grid, 256, SMEM_BYTES, st>>>(p); break;
+        default: gemm_argmax_kernel<0, 2><<<grid, 256, SMEM_BYTES, st>>>(p); break;
+    }
     DIDI_LAUNCH_CHECK();
     argmax_reduce_kernel<<<cdiv(M, 256), 256, 0, st>>>(p.partial, M, p.nchunks, V, ids64, ids32);
     DIDI_LAUNCH_CHECK();

@@ -182,6 +182,40 @@ def test_gemm_epilogues(ops, act, resid):
     assert rel_l2(c, _gemm_ref(a, w, None, None, None)) <= 3e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(2304, 768, 768), (2100, 2304, 768), (2048, 8008, 768), (2050, 576, 3072), (4096, 3072, 128)])
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_gemm_big_tile(ops, M, N, K, precision):
+    """M >= 2048 selects the 256x192 8-wave tile (M and N tails, all epilogue branches)."""
+    a, w, bias, r = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=0.05), rnd(N, seed=23), rnd(M, N, seed=24)
+    a_hi, a_lo = ops.split(a.cuda())
+    w_hi, w_lo = ops.split(w.cuda())
+    rp = ops.split(r.cuda())
+    x3 = precision == "bf16x3"
+    ar, wr = (a, w) if x3 else (a_hi.cpu().float(), w_hi.cpu().float())
+    tol = 3e-5 if x3 else 2e-5
+    c_hi, c_lo, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), precision=precision, out_f32=True)
+    want = _gemm_ref(ar, wr, bias, None, None)
+    assert rel_l2(c, want) <= tol, rel_l2(c, want)
+    assert (c.cpu().double() - want).abs().max().item() <= 50 * tol * want.abs().max().item()
+    assert torch.equal(c_hi.cpu(), c.cpu().to(torch.bfloat16))
+    assert rel_l2(ops.join(c_hi, c_lo), c) <= 2e-5
+    _, _, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), act="gelu", precision=precision, residual_planes=rp,
+                       out_f32=True, out_planes=False)
+    assert rel_l2(c, _gemm_ref(ar, wr, bias, "gelu", ops.join(*rp).cpu())) <= tol
+
+
+def test_gemm_big_tile_identity_asymmetric(ops):
+    M, K = 2304, 192
+    a = torch.zeros(M, K)
+    a[torch.arange(M), torch.arange(M) % K] = 1.0  # row m selects column m % K of W^T
+    w = (torch.arange(768 * K, dtype=torch.float32).reshape(768, K) % 251) - 125  # exact in bf16
+    a_hi, a_lo = ops.split(a.cuda())
+    w_hi, w_lo = ops.split(w.cuda())
+    for precision in ("bf16", "bf16x3"):
+        _, _, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, precision=precision, out_f32=True, out_planes=False)
+        assert torch.equal(c.cpu(), w.t()[torch.arange(M) % K].contiguous())
+
+
 def test_gemm_identity_asymmetric(ops):
     """A = I with an asymmetric W: catches a transposed or permuted C write (exact integers)."""
     K = 128

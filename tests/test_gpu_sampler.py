@@ -160,23 +160,28 @@ def test_torch_noise_loop_equals_native_loop():
 
 def test_full_size_decoder_properties():
     """cfg2-sized model (H=768, 12 layers, 12 heads, FFN 3072; enc 1280/32 heads/5120), S=C=64.
-    (a) a B=2 slice agrees with the CPU oracle; (b) dialogs are independent: the same dialog gives
-    bit-identical output alone and inside a batch of 24 (batch-split invariance)."""
+    (a) a B=2 slice agrees with the CPU oracle; (b) dialogs are independent: the same dialogs give
+    bit-identical output inside batches of 40 and 36 (both on the 256x192 GEMM tile) and the same
+    output to fp32 rounding in a batch of 2 (128x128 tile): batch-split invariance."""
     from didi_amd.config import DiDiConfig
     from didi_amd.synthetic import synthetic_batch, synthetic_state_dict
     from oracle.model import OracleDiDi
 
     cfg = DiDiConfig(diffusion_steps=2000)
     sd = synthetic_state_dict(cfg, seed=1234)
-    ids, mask = synthetic_batch(24, 64, cfg.vocab, seed=3)
+    ids, mask = synthetic_batch(40, 64, cfg.vocab, seed=3)
     g = torch.Generator().manual_seed(9)
-    x_t = torch.randn(24, 64, cfg.dec_dim, generator=g)
-    tids = torch.randint(1, 2001, (24, 1), generator=g)
+    x_t = torch.randn(40, 64, cfg.dec_dim, generator=g)
+    tids = torch.randint(1, 2001, (40, 1), generator=g)
     model = _model(sd, cfg, "bf16x3")
     out, ctx = model(encoder_input_ids=ids.cuda(), encoder_attention_mask=mask.cuda(), decoder_inputs_embeds=x_t.cuda(), time_ids=tids.cuda())
     out2, ctx2 = model(encoder_input_ids=ids[:2].cuda(), encoder_attention_mask=mask[:2].cuda(),
                        decoder_inputs_embeds=x_t[:2].cuda(), time_ids=tids[:2].cuda())
-    assert torch.equal(out[:2], out2) and torch.equal(ctx[:2], ctx2)
+    assert rel_l2(out[:2], out2) <= 1e-6 and rel_l2(ctx[:2], ctx2) <= 1e-6
+    out36, ctx36 = model(encoder_input_ids=ids[:36].cuda(), encoder_attention_mask=mask[:36].cuda(),
+                         decoder_inputs_embeds=x_t[:36].cuda(), time_ids=tids[:36].cuda())
+    assert torch.equal(out[:36], out36) and torch.equal(ctx[:36], ctx36)
+    out, ctx = out.clone(), ctx.clone()
     oracle = OracleDiDi(sd, config_to_oracle_config(cfg))
     want, want_ctx = oracle(encoder_input_ids=ids[:2], encoder_attention_mask=mask[:2], decoder_inputs_embeds=x_t[:2], time_ids=tids[:2])
     e_ctx, e_out = rel_l2(ctx2, want_ctx), rel_l2(out2, want)

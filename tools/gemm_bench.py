@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of didi_gemm_bf16 on the decoder's shapes (M = B*S rows), both precisions.
+
+    python tools/gemm_bench.py [--M 16384] [--iters 30]
+
+Times each (shape, epilogue) as the decoder issues it, with HIP events around `iters`
+back-to-back launches on random data (cdna_hip_programming.md rule 25), and prints algorithmic
+TFLOP/s (2*M*N*K; the bf16x3 passes are not counted) and the executed-MFMA TFLOP/s.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+from didi_amd import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--M", type=int, default=16384)
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--H", type=int, default=768)
+    ap.add_argument("--I", type=int, default=3072)
+    args = ap.parse_args()
+    M, H, I = args.M, args.H, args.I
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)  # noqa: E731
+    shapes = [
+        ("qkv      planes", 3 * H, H, dict()),
+        ("attn_out f32+res", H, H, dict(resid=True)),
+        ("cross_q  planes", H, H, dict()),
+        ("ffn_up   gelu", I, H, dict(act="gelu")),
+        ("ffn_down f32+res", H, I, dict(resid=True)),
+    ]
+    total = {"bf16": 0.0, "bf16x3": 0.0}
+    for name, N, K, kw in shapes:
+        a_hi, a_lo = ops.split(rnd(M, K))
+        w_hi, w_lo = ops.split(rnd(N, K) * 0.02)
+        bias = rnd(N)
+        r = ops.split(rnd(M, N)) if kw.get("resid") else None
+        for prec in ("bf16", "bf16x3"):
+            call = lambda: ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias, act=kw.get("act"), precision=prec,  # noqa: E731
+                                    residual_planes=r, out_f32=bool(r), out_planes=not r, out_lo=prec == "bf16x3")
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / args.iters
+            fl = 2.0 * M * N * K
+            mult = 3 if prec == "bf16x3" else 1
+            total[prec] += us * (2 if name.startswith('attn_out') else 1)
+            print(f"{name:18s} N={N:5d} K={K:5d} {prec:7s} {us:8.1f} us  alg {fl / us / 1e6:7.1f} TF  exec {mult * fl / us / 1e6:7.1f} TF")
+    layer_fl = 2.0 * M * (3 * H * H + 3 * H * H + 2 * H * I)
+    for prec, us in total.items():
+        print(f"sum of 6 GEMMs per layer ({prec}): {us + 0:8.1f} us (cross_out counted as attn_out) -> alg {layer_fl / (us) / 1e6:7.1f} TF")
+
+
+if __name__ == "__main__":
+    main()

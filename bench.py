@@ -163,9 +163,15 @@ def main():
     roofline = None
     if len(dur) == len(flops):
         achieved = sum(flops) / (sum(dur) * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", f"gemm_traffic_{args.precision}.json")
+        if os.path.exists(tpath) and args.batch == 256 and args.seq == 64:  # PMC passes are a separate run (profiles/README.md)
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+            traffic_src = os.path.relpath(tpath, ROOT)
         roofline = {
-            "bound": "mfma", "kernel": "gemm_kernel", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "bound": "mfma", "kernel": f"gemm_big_kernel<{3 if args.precision == 'bf16x3' else 1},4> (256x192 tile)",
+            "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches": len(dur), "avg_launch_us": round(1e3 * sum(dur) / len(dur), 2),
             "avg_gflop_per_launch": round(sum(flops) / len(flops) / 1e9, 2),
             "gemm_share_of_call": round(sum(dur) / (1e3 * elapsed / (args.steps * n_calls)), 3),

@@ -358,18 +358,35 @@ __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_kernel(GemmPara
 // M = 16384 rows the grids are 256 / 768 / 1024 workgroups = 1 / 3 / 4 full rounds of the 256 CUs.
 // 8 waves as 4(M) x 2(N), wave tile 64 x 96 = 4 x 6 MFMA accumulators; one stage = 56 one-KiB
 // LDS-DMA pieces, wave w issues pieces w, w+8, ..., w+48; two stages = 112 KiB, one workgroup per CU.
-#define BBM 256
+//
+// MT = 64-row wave tiles along M: MT = 4 is the 256-row tile above (8 waves, 1 workgroup/CU);
+// MT = 2 is a 128 x 192 tile with 4 waves and 40 KiB stages, two workgroups per CU.
+// What was measured on this loop (M = 16384, bf16x3, K = 3072, N = 768):
+//   MFMAs only (no DMA after the first stage) 157 us, DMA only (no MFMAs) 170 us, both 208 us;
+//   rocprofv3 PMC: MFMA pipe 56 % busy, SQ_WAIT_ANY 37 %, no LDS bank conflicts, L2 hit rate 88 %,
+//   HBM fetch ~320 MB (A is fetched once: the four column tiles of a row band share it in L2).
+//   The L2->LDS stream runs at ~8 TB/s chip-wide whatever carries it: LDS-DMA, register staging
+//   (T14), both stages in flight (early stage release), MT = 2, a touch-ahead L2 prefetch and
+//   padded leading dimensions were all within +-4 % of this form or slower, so it stays.
 #define BBN 192
-#define BIG_STAGE_BYTES 57344
-template <int NPASS>
-__global__ void __launch_bounds__(512, 2) gemm_big_kernel(GemmParams p) {
+template <int MT> struct BigGeom {
+    static constexpr int BM_ = MT * 64, WAVES = MT * 2, THREADS = WAVES * 64;
+    static constexpr int A_BYTES = MT * 64 * 128;       // A region: [BM][128 B], or hi+lo tiles of [BM][64 B]
+    static constexpr int NA = A_BYTES / 1024, NW = 24;  // 1-KiB DMA pieces per region
+    static constexpr int STAGE = A_BYTES + NW * 1024;
+    static constexpr int PPW = (NA + NW) / WAVES;       // pieces per wave per stage
+};
+template <int NPASS, int MT>
+__global__ void __launch_bounds__(BigGeom<MT>::THREADS, 2) gemm_big_kernel(GemmParams p) {
+    using G = BigGeom<MT>;
     constexpr int BKK = NPASS == 3 ? 32 : 64;
     constexpr int ROWB = BKK * 2, CPR = ROWB / 16, RPI = 64 / CPR;
-    constexpr int W_OFF = 32768;                        // W tile(s) start (A region = 32 KiB for both precisions)
-    constexpr int LO_A = 16384, LO_W = 12288;           // bf16x3: offset of the lo tile after its hi tile
+    constexpr int W_OFF = G::A_BYTES;                   // W tile(s) start
+    constexpr int LO_A = G::A_BYTES / 2, LO_W = 12288;  // bf16x3: offset of the lo tile after its hi tile
+    constexpr int NA = G::NA, PPW = G::PPW, WAVES = G::WAVES, BIG_STAGE_BYTES = G::STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / p.tiles_n) * BBM, n0 = (tile % p.tiles_n) * BBN;
+    const int m0 = (tile / p.tiles_n) * G::BM_, n0 = (tile % p.tiles_n) * BBN;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -381,23 +398,23 @@ __global__ void __launch_bounds__(512, 2) gemm_big_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // DMA piece q = wave + 8j (1 KiB at stage offset q*1024): which operand plane, which rows
-    const u16* src[7];
+    // DMA piece q = wave + WAVES*j (1 KiB at stage offset q*1024): which operand plane, which rows
+    const u16* src[PPW];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const int q = wave + 8 * j;
+    for (int j = 0; j < PPW; ++j) {
+        const int q = wave + WAVES * j;
         const u16* base;
         int row, ld, lim, r0;
         if (NPASS == 3) {
-            if (q < 16) { base = p.A_hi; row = q * RPI; }
-            else if (q < 32) { base = p.A_lo; row = (q - 16) * RPI; }
-            else if (q < 44) { base = p.W_hi; row = (q - 32) * RPI; }
-            else { base = p.W_lo; row = (q - 44) * RPI; }
+            if (q < NA / 2) { base = p.A_hi; row = q * RPI; }
+            else if (q < NA) { base = p.A_lo; row = (q - NA / 2) * RPI; }
+            else if (q < NA + 12) { base = p.W_hi; row = (q - NA) * RPI; }
+            else { base = p.W_lo; row = (q - NA - 12) * RPI; }
         } else {
-            if (q < 32) { base = p.A_hi; row = q * RPI; }
-            else { base = p.W_hi; row = (q - 32) * RPI; }
+            if (q < NA) { base = p.A_hi; row = q * RPI; }
+            else { base = p.W_hi; row = (q - NA) * RPI; }
         }
-        if (q < 32) { ld = p.lda; lim = p.M - 1; r0 = m0; } else { ld = p.ldw; lim = p.N - 1; r0 = n0; }
+        if (q < NA) { ld = p.lda; lim = p.M - 1; r0 = m0; } else { ld = p.ldw; lim = p.N - 1; r0 = n0; }
         row += lane / CPR;
         const int slot = lane % CPR;
         const int g = NPASS == 3 ? (slot ^ ((0 - (row >> 2)) & 3)) : (slot ^ (row & 7));
@@ -407,7 +424,7 @@ __global__ void __launch_bounds__(512, 2) gemm_big_kernel(GemmParams p) {
     auto issue = [&](int t, int buf) {
         char* st = smem + buf * BIG_STAGE_BYTES + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) glds16(src[j] + t * BKK, st + j * 8192);
+        for (int j = 0; j < PPW; ++j) glds16(src[j] + t * BKK, st + j * WAVES * 1024);
     };
 
     issue(0, 0);
@@ -498,12 +515,25 @@ static bool gemm_big_enabled() {
     static const bool v = [] { const char* e = getenv("DIDI_GEMM_BIG"); return e ? atoi(e) != 0 : true; }();
     return v;
 }
+// experiment knob: DIDI_GEMM_MT=2 selects the 128-row, 4-wave form of the big tile (default 4: measured faster)
+static int gemm_big_mt() {
+    static const int v = [] { const char* e = getenv("DIDI_GEMM_MT"); return e && atoi(e) == 2 ? 2 : 4; }();
+    return v;
+}
+template <int NPASS, int MT>
+static bool opt_in_lds() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<NPASS, MT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<MT>::STAGE) == hipSuccess;
+}
 static bool allow_big_lds() {  // > 64 KiB of dynamic LDS needs an opt-in, once per process
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<3>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BIG_STAGE_BYTES) == hipSuccess &&
-                           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<1>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BIG_STAGE_BYTES) == hipSuccess;
+    static const bool ok = opt_in_lds<3, 4>() && opt_in_lds<1, 4>() && opt_in_lds<3, 2>() && opt_in_lds<1, 2>();
     return ok;
+}
+template <int NPASS, int MT>
+static void launch_big(GemmParams& p, hipStream_t st) {
+    using G = BigGeom<MT>;
+    p.tiles_m = cdiv(p.M, G::BM_);
+    gemm_big_kernel<NPASS, MT><<<p.tiles_m * p.tiles_n, G::THREADS, 2 * G::STAGE, st>>>(p);
 }
 
 static inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -535,10 +565,10 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
                      (long)big_tiles_n * BBN * 100 <= (long)a->N * 115;  // <= 15 % padded columns
     if (big) {
         if (!allow_big_lds()) return DIDI_ERR_LAUNCH;
-        p.tiles_m = cdiv(a->M, BBM); p.tiles_n = big_tiles_n;
-        const int grid = p.tiles_m * p.tiles_n;
-        if (mode == 3) gemm_big_kernel<3><<<grid, 512, 2 * BIG_STAGE_BYTES, st>>>(p);
-        else gemm_big_kernel<1><<<grid, 512, 2 * BIG_STAGE_BYTES, st>>>(p);
+        p.tiles_n = big_tiles_n;
+        const bool mt4 = gemm_big_mt() == 4;
+        if (mode == 3) { if (mt4) launch_big<3, 4>(p, st); else launch_big<3, 2>(p, st); }
+        else { if (mt4) launch_big<1, 4>(p, st); else launch_big<1, 2>(p, st); }
     } else {
         p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
         const int grid = p.tiles_m * p.tiles_n;

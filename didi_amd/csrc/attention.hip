@@ -1,19 +1,28 @@
-// LDS-resident fused attention for short dialogs (Sq, Sk <= 96, head dim 32/64).
+// LDS-resident fused attention for short dialogs (Sq, Sk <= 96, head dim <= 64).
 //
-// One 256-thread workgroup per (dialog, head).  Q, K and V^T of that pair are staged in LDS once
-// (bf16 planes, zero-padded to MFMA granularity), then each wave owns 16-query blocks:
-//   scores  S = Q K^T          v_mfma_f32_16x16x32_bf16, A-operand = Q rows, B-operand = K rows
-//                              -> lane holds S[q = 4*(lane>>4)+r][key = 16*kt + (lane&15)]
-//   softmax in registers       row max / row sum: in-lane over key tiles, then a 16-lane butterfly
-//   P -> LDS (per-wave strip)  so that P can be re-read as the A-operand (8 consecutive keys/lane)
-//   O = P V                    B-operand = rows of V^T (V is transposed while it is staged, so the
-//                              8 keys a lane needs are one 16-byte LDS read)
+// One 256-thread workgroup per (dialog, head).  K and V of that pair are staged ROW-MAJOR in LDS
+// once (bf16 planes, zero-padded to MFMA granularity, XOR-swizzled 16-byte chunks instead of row
+// padding); Q never touches LDS.  Each wave owns 16-query blocks and runs them without any
+// workgroup barrier:
+//   scores, transposed   S^T = K Q^T    v_mfma_f32_16x16x32_bf16, A-operand = K rows (ds_read_b128),
+//                                       B-operand = Q rows read straight from global memory
+//                                       -> lane holds S[q = lane&15][key = 16*kt + 4*(lane>>4) + r]
+//   softmax in registers                one query per lane: row max / row sum in-lane over the key
+//                                       tiles, then two cross-lane steps (xor 16, 32)
+//   O^T = V^T P^T                       the probabilities a lane holds ARE its B-operand elements
+//                                       (k index = the lane's own keys), and the matching V^T
+//                                       A-operand comes from the row-major V image through
+//                                       ds_read_b64_tr_b16 (hardware transpose): no V^T staging,
+//                                       no round trip of P through LDS
+//                                       -> lane holds O[q = lane&15][d = 16*dt + 4*(lane>>4) + r]:
+//                                       4 consecutive columns, one 8-byte store per plane
 // fp32 everywhere except the MFMA operands.  In bf16x3 precision every product is three MFMAs
 // (lo*hi, hi*lo, hi*hi) on split planes, P included.
 //
 // Masking follows HF's additive-mask semantics (see include/didi_hip.h): masked (causal or padded
 // context) keys take the most negative finite float; LDS padding keys are excluded outright.
-// LDS rows are padded by 16 bytes to spread ds_read_b128 over the banks.
+//
+// ds_read_b64_tr_b16 needs EXEC all ones: every branch around it below is wave-uniform.
 #include "common.hpp"
 
 struct AttnParams {
@@ -29,173 +38,215 @@ struct AttnParams {
     int d;       // true head dim (multiple of 8, <= D); columns d..D-1 are zero padding in LDS
 };
 
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+
+// Byte offset of 16-byte chunk `ch` of row `row` in a [rows][D] bf16 LDS image.  The XOR makes both
+// the ds_read_b128 row reads of the 16x16x32 A-operand and the transposed reads conflict-free
+// (same swizzles as the GEMM's 128-byte and 64-byte rows).
+template <int D>
+__device__ __forceinline__ int img_off(int row, int ch) {
+    if constexpr (D == 64) return row * 128 + ((ch ^ (row & 7)) << 4);
+    else return row * 64 + ((ch ^ ((-(row >> 2)) & 3)) << 4);
+}
+
+__device__ __forceinline__ v4s lds_tr_read(const char* ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)ptr);
+}
+
+__device__ __forceinline__ bf16x8 cat8(v4s a, v4s b) {
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__device__ __forceinline__ bf16x8 ld_q(const u16* q, bool ok) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ok) v = *reinterpret_cast<const uint4*>(q);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 template <int D, int NPASS>
 __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
     constexpr int NPL = NPASS == 3 ? 2 : 1;
-    constexpr int QS = D * 2 + 16;  // bytes per Q/K row in LDS
+    constexpr int CH = D / 8;   // 16-byte chunks per row
+    constexpr int KS = D / 32;  // MFMA k-steps over the head dim
     constexpr float NEG = -3.4028234663852886e38f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int head = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
-    const int SP = p.SP, CP = p.CP;
-    const int VS = CP * 2 + 16;  // bytes per V^T row / P row
-    char* Qs = smem;
-    char* Ks = Qs + NPL * SP * QS;
-    char* Vt = Ks + NPL * CP * QS;
-    char* Ps = Vt + NPL * D * VS;
-    int* mk = reinterpret_cast<int*>(Ps + 4 * NPL * 16 * VS);  // [CP] 0 visible, 1 masked, 2 padding
+    const int CP = p.CP;
+    const int plane = CP * D * 2;  // bytes per K / V plane image
+    char* Ks = smem;
+    char* Vs = Ks + NPL * plane;
+    int* mk = reinterpret_cast<int*>(Vs + NPL * plane);  // [CP] 0 visible, 1 masked, 2 padding
 
-    // ---- stage Q, K, V^T, mask
-    constexpr int CH = D / 8;  // 16-byte chunks per row
-    for (int pl = 0; pl < NPL; ++pl) {
-        const u16* q = p.Q[pl] + (size_t)b * p.Sq * p.ldq + head * p.d;
-        for (int i = tid; i < SP * CH; i += 256) {
-            const int r = i / CH, c = i % CH;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (r < p.Sq && c * 8 < p.d) v = *reinterpret_cast<const uint4*>(q + (size_t)r * p.ldq + c * 8);
-            *reinterpret_cast<uint4*>(Qs + pl * SP * QS + r * QS + c * 16) = v;
-        }
-        const u16* k = p.K[pl] + (size_t)b * p.Sk * p.ldk + head * p.d;
-        const u16* vv = p.V[pl] + (size_t)b * p.Sk * p.ldv + head * p.d;
-        for (int i = tid; i < CP * CH; i += 256) {
-            const int r = i / CH, c = i % CH;
-            uint4 kv = make_uint4(0, 0, 0, 0), v4 = make_uint4(0, 0, 0, 0);
-            if (r < p.Sk && c * 8 < p.d) {
-                kv = *reinterpret_cast<const uint4*>(k + (size_t)r * p.ldk + c * 8);
-                v4 = *reinterpret_cast<const uint4*>(vv + (size_t)r * p.ldv + c * 8);
-            }
-            *reinterpret_cast<uint4*>(Ks + pl * CP * QS + r * QS + c * 16) = kv;
-            const uint32_t w[4] = {v4.x, v4.y, v4.z, v4.w};
-            char* vt = Vt + pl * D * VS + r * 2;
+    const int nqb = p.SP / 16;
+    const int nkt_real = (p.Sk + 15) / 16;
+    const u16* qh_base = p.Q[0] + (size_t)b * p.Sq * p.ldq + head * p.d;
+    const u16* ql_base = NPL == 2 ? p.Q[1] + (size_t)b * p.Sq * p.ldq + head * p.d : nullptr;
+
+    // ---- Q fragments of this wave's first block: global -> registers, in flight during the staging
+    bf16x8 qh0, qh1, ql0, ql1;
+    qh0 = qh1 = ql0 = ql1 = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+#define DIDI_LOAD_Q(qb_)                                                              \
+    do {                                                                              \
+        const int q_ = (qb_) * 16 + lr;                                               \
+        const size_t ro_ = (size_t)q_ * p.ldq;                                        \
+        const bool ok0_ = q_ < p.Sq && lg * 8 < p.d;                                  \
+        const bool ok1_ = q_ < p.Sq && 32 + lg * 8 < p.d;                             \
+        qh0 = ld_q(qh_base + ro_ + lg * 8, ok0_);                                     \
+        if constexpr (KS == 2) qh1 = ld_q(qh_base + ro_ + 32 + lg * 8, ok1_);         \
+        if constexpr (NPL == 2) {                                                     \
+            ql0 = ld_q(ql_base + ro_ + lg * 8, ok0_);                                 \
+            if constexpr (KS == 2) ql1 = ld_q(ql_base + ro_ + 32 + lg * 8, ok1_);     \
+        }                                                                             \
+    } while (0)
+    if (wave < nqb) DIDI_LOAD_Q(wave);
+
+    // ---- stage K, V (all global loads first, then the LDS writes) and the key flags
+    {
+        uint4 kr[3][NPL], vr[3][NPL];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const u16 x = (u16)(w[e >> 1] >> ((e & 1) * 16));
-                *reinterpret_cast<u16*>(vt + (c * 8 + e) * VS) = x;
+        for (int j = 0; j < 3; ++j) {
+            const int i = tid + j * 256;
+            const int r = i / CH, c = i % CH;
+            const bool ok = r < p.Sk && c * 8 < p.d;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                kr[j][pl] = make_uint4(0, 0, 0, 0);
+                vr[j][pl] = make_uint4(0, 0, 0, 0);
+                if (ok) {
+                    kr[j][pl] = *reinterpret_cast<const uint4*>(p.K[pl] + ((size_t)b * p.Sk + r) * p.ldk + head * p.d + c * 8);
+                    vr[j][pl] = *reinterpret_cast<const uint4*>(p.V[pl] + ((size_t)b * p.Sk + r) * p.ldv + head * p.d + c * 8);
+                }
             }
         }
-    }
-    for (int c = tid; c < CP; c += 256) {
-        int f = 0;
-        if (c >= p.Sk) f = 2;
-        else if (p.key_mask && p.key_mask[(size_t)b * p.Sk + c] == 0) f = 1;
-        mk[c] = f;
+        for (int c = tid; c < CP; c += 256) {
+            int f = 0;
+            if (c >= p.Sk) f = 2;
+            else if (p.key_mask && p.key_mask[(size_t)b * p.Sk + c] == 0) f = 1;
+            mk[c] = f;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i = tid + j * 256;
+            const int r = i / CH, c = i % CH;
+            if (r < CP) {
+                const int o = img_off<D>(r, c);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    *reinterpret_cast<uint4*>(Ks + pl * plane + o) = kr[j][pl];
+                    *reinterpret_cast<uint4*>(Vs + pl * plane + o) = vr[j][pl];
+                }
+            }
+        }
     }
     __syncthreads();
 
-    const int nqb = SP / 16;
-    const int nkt_real = (p.Sk + 15) / 16;
-    char* Pw = Ps + wave * NPL * 16 * VS;
-    for (int it = 0; it * 4 < nqb; ++it) {
-        const int qb = it * 4 + wave;
-        const bool active = qb < nqb;
-        const int nkt = active ? (p.causal ? min(qb + 1, nkt_real) : nkt_real) : 0;
+    u16* oh = p.O[0] + (size_t)b * p.Sq * p.ldo + head * p.d;
+    u16* ol = NPL == 2 ? p.O[1] + (size_t)b * p.Sq * p.ldo + head * p.d : nullptr;
+
+    for (int qb = wave; qb < nqb; qb += 4) {
+        if (qb != wave) DIDI_LOAD_Q(qb);
+        const int nkt = p.causal ? min(qb + 1, nkt_real) : nkt_real;
         const int nks = (nkt + 1) / 2;
+        const int q = qb * 16 + lr;
         float sc[6][4];
-        float rmax[4] = {NEG, NEG, NEG, NEG}, rsum[4] = {0.f, 0.f, 0.f, 0.f};
-        // ---- scores
+        float rmax = NEG, rsum = 0.f;
+        // ---- scores: lane holds S[q][16*kt + 4*lg + r]
 #pragma unroll
         for (int kt = 0; kt < 6; ++kt) {
             if (kt < nkt) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < D / 32; ++ks) {
-                    const int qo = (qb * 16 + lr) * QS + (ks * 4 + lg) * 16;
-                    const int ko = (kt * 16 + lr) * QS + (ks * 4 + lg) * 16;
-                    const bf16x8 qh = *reinterpret_cast<const bf16x8*>(Qs + qo);
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int ko = img_off<D>(kt * 16 + lr, ks * 4 + lg);
                     const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Ks + ko);
+                    const bf16x8 qh = ks ? qh1 : qh0;
                     if constexpr (NPASS == 3) {
-                        const bf16x8 ql = *reinterpret_cast<const bf16x8*>(Qs + SP * QS + qo);
-                        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Ks + CP * QS + ko);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql, kh, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, kl, acc, 0, 0, 0);
+                        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Ks + plane + ko);
+                        const bf16x8 ql = ks ? ql1 : ql0;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql, acc, 0, 0, 0);
                     }
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, kh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh, acc, 0, 0, 0);
                 }
-                const int key = kt * 16 + lr;
-                const int f = mk[key];
+                const int4 f4 = *reinterpret_cast<const int4*>(mk + kt * 16 + lg * 4);
+                const int fl[4] = {f4.x, f4.y, f4.z, f4.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = qb * 16 + lg * 4 + r;
+                    const int key = kt * 16 + lg * 4 + r;
                     float s = acc[r] * p.scale;
-                    if (f == 1 || (p.causal && key > q)) s = NEG;
-                    if (f == 2) s = -INFINITY;
+                    if (fl[r] == 1 || (p.causal && key > q)) s = NEG;
+                    if (fl[r] == 2) s = -INFINITY;
                     sc[kt][r] = s;
-                    rmax[r] = fmaxf(rmax[r], s);
+                    rmax = fmaxf(rmax, s);
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sc[kt][r] = -INFINITY;
             }
         }
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 16, 64));
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+        // ---- probabilities (unnormalised; the row sum divides O at the end) -> B-operand fragments:
+        //      k-step s, element e: key 32*s + 16*(e>>2) + 4*lg + (e&3)
+        v8s ph[3], pl[3];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int s = 0; s < 3; ++s) {
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) rmax[r] = fmaxf(rmax[r], __shfl_xor(rmax[r], o, 64));
-        }
-        // ---- probabilities -> LDS strip (unnormalised; the row sum divides O at the end)
-#pragma unroll
-        for (int kt = 0; kt < 6; ++kt) {
-            if (kt < 2 * nks) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pr = (kt < nkt) ? expf(sc[kt][r] - rmax[r]) : 0.f;
-                    rsum[r] += pr;
-                    u16 h, l;
-                    split2(pr, h, l);
-                    const int po = (lg * 4 + r) * VS + (kt * 16 + lr) * 2;
-                    *reinterpret_cast<u16*>(Pw + po) = h;
-                    if constexpr (NPASS == 3) *reinterpret_cast<u16*>(Pw + 16 * VS + po) = l;
-                }
+            for (int e = 0; e < 8; ++e) {
+                const int kt = 2 * s + (e >> 2);
+                const float pr = (kt < nkt) ? expf(sc[kt][e & 3] - rmax) : 0.f;
+                rsum += pr;
+                u16 h, l;
+                split2(pr, h, l);
+                ph[s][e] = (short)h;
+                pl[s][e] = (short)l;
             }
         }
+        rsum += __shfl_xor(rsum, 16, 64);
+        rsum += __shfl_xor(rsum, 32, 64);
+        const float rinv = 1.0f / rsum;
+        // ---- O^T = V^T P^T; A-operand element e of lane (lr, lg) = V[key(s, lg, e)][16*dt + lr]
+        const int trow = 4 * lg + (lr >> 2);  // row of the 4x16 block this lane addresses
+        const int tsub = 8 * (lr & 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int dt = 0; dt < D / 16; ++dt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int cch = 2 * dt + ((lr & 3) >> 1);
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) rsum[r] += __shfl_xor(rsum[r], o, 64);
-        }
-        __syncthreads();
-        // ---- O = P V
-        if (active) {
-            u16* oh = p.O[0] + (size_t)b * p.Sq * p.ldo + head * p.d;
-            u16* ol = NPL == 2 ? p.O[1] + (size_t)b * p.Sq * p.ldo + head * p.d : nullptr;
-#pragma unroll
-            for (int dt = 0; dt < D / 16; ++dt) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                for (int ks = 0; ks < nks; ++ks) {
-                    const int po = lr * VS + (ks * 4 + lg) * 16;
-                    const int vo = (dt * 16 + lr) * VS + (ks * 4 + lg) * 16;
-                    const bf16x8 ph = *reinterpret_cast<const bf16x8*>(Pw + po);
-                    const bf16x8 vh = *reinterpret_cast<const bf16x8*>(Vt + vo);
+            for (int s = 0; s < 3; ++s) {
+                if (s < nks) {
+                    const int o0 = img_off<D>(32 * s + trow, cch) + tsub;
+                    const int o1 = img_off<D>(32 * s + 16 + trow, cch) + tsub;
+                    const bf16x8 vh = cat8(lds_tr_read(Vs + o0), lds_tr_read(Vs + o1));
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, ph[s]);
                     if constexpr (NPASS == 3) {
-                        const bf16x8 pl = *reinterpret_cast<const bf16x8*>(Pw + 16 * VS + po);
-                        const bf16x8 vl = *reinterpret_cast<const bf16x8*>(Vt + D * VS + vo);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl, acc, 0, 0, 0);
+                        const bf16x8 vl = cat8(lds_tr_read(Vs + plane + o0), lds_tr_read(Vs + plane + o1));
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, pl[s]);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, bh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, bl, acc, 0, 0, 0);
                     }
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh, acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = qb * 16 + lg * 4 + r;
-                    if (q < p.Sq && dt * 16 + lr < p.d) {
-                        const float o = acc[r] / rsum[r];
-                        u16 h, l;
-                        split2(o, h, l);
-                        const size_t off = (size_t)q * p.ldo + dt * 16 + lr;
-                        oh[off] = h;
-                        if (ol) ol[off] = l;
-                    }
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, bh, acc, 0, 0, 0);
                 }
             }
+            const int d0 = dt * 16 + lg * 4;
+            if (q < p.Sq && d0 < p.d) {
+                const float o[4] = {acc[0] * rinv, acc[1] * rinv, acc[2] * rinv, acc[3] * rinv};
+                uint2 h2, l2;
+                split4(o, h2, l2);
+                const size_t off = (size_t)q * p.ldo + d0;
+                *reinterpret_cast<uint2*>(oh + off) = h2;
+                if (ol) *reinterpret_cast<uint2*>(ol + off) = l2;
+            }
         }
-        __syncthreads();
     }
+#undef DIDI_LOAD_Q
 }
 
-static size_t attn_lds_bytes(int D, int npl, int SP, int CP) {
-    const size_t QS = D * 2 + 16, VS = CP * 2 + 16;
-    return npl * SP * QS + npl * CP * QS + npl * D * VS + 4 * npl * 16 * VS + CP * sizeof(int);
+static size_t attn_lds_bytes(int D, int npl, int CP) {
+    return (size_t)2 * npl * CP * D * 2 + CP * sizeof(int);
 }
 
 extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
@@ -204,12 +255,13 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
     if (a->D < 8 || a->D > 64 || a->D % 8 != 0 || a->Sq > 96 || a->Sk > 96) return DIDI_ERR_UNSUPPORTED;
     const int DP = a->D <= 32 ? 32 : 64;  // head dim padded to the MFMA K granularity
     if (a->causal && a->Sq != a->Sk) return DIDI_ERR_BAD_ARG;
-    DIDI_CHECK_ARG(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo > 0);
+    DIDI_CHECK_ARG(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo > 0 && a->ldo % 4 == 0);
     const bool x3 = a->precision == DIDI_PREC_BF16X3;
     DIDI_CHECK_ARG(x3 || a->precision == DIDI_PREC_BF16);
     if (x3) DIDI_CHECK_ARG(a->Q_lo && a->K_lo && a->V_lo && a->O_lo);
     const void* ptrs[6] = {a->Q_hi, a->Q_lo, a->K_hi, a->K_lo, a->V_hi, a->V_lo};
     for (const void* q : ptrs) DIDI_CHECK_ARG((reinterpret_cast<uintptr_t>(q) & 15) == 0);
+    DIDI_CHECK_ARG((reinterpret_cast<uintptr_t>(a->O_hi) & 7) == 0 && (reinterpret_cast<uintptr_t>(a->O_lo) & 7) == 0);
     if (a->B == 0) return DIDI_OK;
     AttnParams p{};
     p.B = a->B; p.heads = a->heads; p.Sq = a->Sq; p.Sk = a->Sk;
@@ -220,20 +272,16 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
     p.O[0] = a->O_hi; p.O[1] = x3 ? a->O_lo : nullptr; p.ldo = a->ldo;
     p.SP = (a->Sq + 15) / 16 * 16;
     p.CP = (a->Sk + 31) / 32 * 32;
-    const size_t lds = attn_lds_bytes(DP, x3 ? 2 : 1, p.SP, p.CP);
+    const size_t lds = attn_lds_bytes(DP, x3 ? 2 : 1, p.CP);  // <= 48.4 KiB: 3-4 workgroups per CU
     dim3 grid(a->heads, a->B);
     hipStream_t st = as_stream(stream);
-#define DIDI_ATTN_LAUNCH(DD, NP)                                                                          \
-    do {                                                                                                  \
-        if (lds > 65536 &&                                                                                \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DD, NP>),                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)      \
-            return DIDI_ERR_LAUNCH;                                                                       \
-        attn_kernel<DD, NP><<<grid, 256, lds, st>>>(p);                                                   \
-    } while (0)
-    if (DP == 64) { if (x3) DIDI_ATTN_LAUNCH(64, 3); else DIDI_ATTN_LAUNCH(64, 1); }
-    else { if (x3) DIDI_ATTN_LAUNCH(32, 3); else DIDI_ATTN_LAUNCH(32, 1); }
-#undef DIDI_ATTN_LAUNCH
+    if (DP == 64) {
+        if (x3) attn_kernel<64, 3><<<grid, 256, lds, st>>>(p);
+        else attn_kernel<64, 1><<<grid, 256, lds, st>>>(p);
+    } else {
+        if (x3) attn_kernel<32, 3><<<grid, 256, lds, st>>>(p);
+        else attn_kernel<32, 1><<<grid, 256, lds, st>>>(p);
+    }
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

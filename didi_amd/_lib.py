@@ -18,7 +18,8 @@ i32p = C.POINTER(C.c_int32)
 i64p = C.POINTER(C.c_int64)
 
 OK = 0
-PREC_BF16, PREC_BF16X3 = 1, 3
+PREC_BF16, PREC_FP16, PREC_BF16X3 = 1, 2, 3
+FMT_BF16, FMT_FP16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_TANH = 0, 1, 2
 STEP_NONE, STEP_INIT, STEP_DDPM, STEP_EULER = 0, 1, 2, 3
 
@@ -32,7 +33,7 @@ class StepArgs(C.Structure):
         ("x_out", C.c_void_p), ("xin_out", C.c_void_p),
         ("time_embeds", C.c_void_p), ("t", C.c_int), ("time_idx", C.c_void_p),
         ("pos_emb", C.c_void_p), ("tok_type0", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
-        ("ln_eps", C.c_float), ("h_hi", C.c_void_p), ("h_lo", C.c_void_p),
+        ("ln_eps", C.c_float), ("h_hi", C.c_void_p), ("h_lo", C.c_void_p), ("plane_format", C.c_int),
     ]
 
 
@@ -109,12 +110,13 @@ SYMBOLS = [
     ("didi_version", C.c_int, []),
     ("didi_error_string", C.c_char_p, [C.c_int]),
     ("didi_split_bf16", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("didi_split_fp16", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("didi_philox_normal", C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]),
     ("didi_step_embed_ln", C.c_int, [C.POINTER(StepArgs), C.c_void_p]),
     ("didi_embed_gather", C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p]),
     ("didi_layernorm", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p,
-                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     ("didi_gemm_bf16", C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     ("didi_round_argmax_bytes", C.c_size_t, [C.c_int, C.c_int]),
     ("didi_round_argmax", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -147,8 +149,8 @@ def _load():
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.didi_version() != 1:
-        raise ImportError(f"libdidi_hip ABI version {lib.didi_version()} != 1")
+    if lib.didi_version() != 2:
+        raise ImportError(f"libdidi_hip ABI version {lib.didi_version()} != 2")
     return lib
 
 

@@ -64,7 +64,7 @@ __device__ __forceinline__ bf16x8 ld_q(const u16* q, bool ok) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int D, int NPASS>
+template <int D, int NPASS, bool F16>
 __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
     constexpr int NPL = NPASS == 3 ? 2 : 1;
     constexpr int CH = D / 8;   // 16-byte chunks per row
@@ -166,10 +166,10 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
                     if constexpr (NPASS == 3) {
                         const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Ks + plane + ko);
                         const bf16x8 ql = ks ? ql1 : ql0;
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql, acc, 0, 0, 0);
+                        acc = mma16<F16>(kl, qh, acc);
+                        acc = mma16<F16>(kh, ql, acc);
                     }
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh, acc, 0, 0, 0);
+                    acc = mma16<F16>(kh, qh, acc);
                 }
                 const int4 f4 = *reinterpret_cast<const int4*>(mk + kt * 16 + lg * 4);
                 const int fl[4] = {f4.x, f4.y, f4.z, f4.w};
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
                 const float pr = (kt < nkt) ? expf(sc[kt][e & 3] - rmax) : 0.f;
                 rsum += pr;
                 u16 h, l;
-                split2(pr, h, l);
+                split2(pr, h, l, F16);
                 ph[s][e] = (short)h;
                 pl[s][e] = (short)l;
             }
@@ -225,17 +225,17 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
                     if constexpr (NPASS == 3) {
                         const bf16x8 vl = cat8(lds_tr_read(Vs + plane + o0), lds_tr_read(Vs + plane + o1));
                         const bf16x8 bl = __builtin_bit_cast(bf16x8, pl[s]);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, bh, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, bl, acc, 0, 0, 0);
+                        acc = mma16<F16>(vl, bh, acc);
+                        acc = mma16<F16>(vh, bl, acc);
                     }
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, bh, acc, 0, 0, 0);
+                    acc = mma16<F16>(vh, bh, acc);
                 }
             }
             const int d0 = dt * 16 + lg * 4;
             if (q < p.Sq && d0 < p.d) {
                 const float o[4] = {acc[0] * rinv, acc[1] * rinv, acc[2] * rinv, acc[3] * rinv};
                 uint2 h2, l2;
-                split4(o, h2, l2);
+                split4(o, h2, l2, F16);
                 const size_t off = (size_t)q * p.ldo + d0;
                 *reinterpret_cast<uint2*>(oh + off) = h2;
                 if (ol) *reinterpret_cast<uint2*>(ol + off) = l2;
@@ -257,7 +257,8 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
     if (a->causal && a->Sq != a->Sk) return DIDI_ERR_BAD_ARG;
     DIDI_CHECK_ARG(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo > 0 && a->ldo % 4 == 0);
     const bool x3 = a->precision == DIDI_PREC_BF16X3;
-    DIDI_CHECK_ARG(x3 || a->precision == DIDI_PREC_BF16);
+    const bool f16 = a->precision == DIDI_PREC_FP16;
+    DIDI_CHECK_ARG(x3 || f16 || a->precision == DIDI_PREC_BF16);
     if (x3) DIDI_CHECK_ARG(a->Q_lo && a->K_lo && a->V_lo && a->O_lo);
     const void* ptrs[6] = {a->Q_hi, a->Q_lo, a->K_hi, a->K_lo, a->V_hi, a->V_lo};
     for (const void* q : ptrs) DIDI_CHECK_ARG((reinterpret_cast<uintptr_t>(q) & 15) == 0);
@@ -276,11 +277,13 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
     dim3 grid(a->heads, a->B);
     hipStream_t st = as_stream(stream);
     if (DP == 64) {
-        if (x3) attn_kernel<64, 3><<<grid, 256, lds, st>>>(p);
-        else attn_kernel<64, 1><<<grid, 256, lds, st>>>(p);
+        if (x3) attn_kernel<64, 3, false><<<grid, 256, lds, st>>>(p);
+        else if (f16) attn_kernel<64, 1, true><<<grid, 256, lds, st>>>(p);
+        else attn_kernel<64, 1, false><<<grid, 256, lds, st>>>(p);
     } else {
-        if (x3) attn_kernel<32, 3><<<grid, 256, lds, st>>>(p);
-        else attn_kernel<32, 1><<<grid, 256, lds, st>>>(p);
+        if (x3) attn_kernel<32, 3, false><<<grid, 256, lds, st>>>(p);
+        else if (f16) attn_kernel<32, 1, true><<<grid, 256, lds, st>>>(p);
+        else attn_kernel<32, 1, false><<<grid, 256, lds, st>>>(p);
     }
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;

@@ -6,6 +6,7 @@
 #include "../../include/didi_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short u16;
 
@@ -19,32 +20,51 @@ typedef unsigned short u16;
         if (hipGetLastError() != hipSuccess) return DIDI_ERR_LAUNCH; \
     } while (0)
 
-// ---- split-bf16 representation -------------------------------------------------------------
-// An fp32 value x travels as two bf16 planes: hi = bf16(x) (round-to-nearest-even) and
-// lo = bf16(x - hi).  hi + lo carries ~16 mantissa bits.  "bf16" GEMM mode multiplies hi planes
-// only; "bf16x3" mode adds the hi*lo and lo*hi cross terms into the same fp32 accumulator.
+// ---- split 16-bit planes ----------------------------------------------------------------------
+// An fp32 value x travels as two 16-bit planes: hi = rne16(x) and lo = rne16(x - hi).
+//   bf16 planes (f16 == 0): hi + lo carries ~16 mantissa bits.  "bf16" GEMM mode multiplies hi planes
+//     only; "bf16x3" adds the hi*lo and lo*hi cross terms into the same fp32 accumulator.
+//   fp16 planes (f16 != 0): hi alone carries 11 bits (8x finer than bf16) and feeds the one-product
+//     "fp16" mode; lo is kept only where a value is re-joined (residual adds): hi + lo ~ 22 bits.
 __device__ __forceinline__ u16 bf16_bits(float x) { return __builtin_bit_cast(u16, (__bf16)x); }
 __device__ __forceinline__ float bf16_to_f32(u16 b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+__device__ __forceinline__ u16 f16_bits(float x) { return __builtin_bit_cast(u16, (_Float16)x); }
+__device__ __forceinline__ float f16_to_f32(u16 b) { return (float)__builtin_bit_cast(_Float16, b); }
 
-__device__ __forceinline__ void split2(float x, u16& hi, u16& lo) {
-    hi = bf16_bits(x);
-    lo = bf16_bits(x - bf16_to_f32(hi));
+__device__ __forceinline__ void split2(float x, u16& hi, u16& lo, int f16 = 0) {
+    if (f16) {
+        hi = f16_bits(x);
+        lo = f16_bits(x - f16_to_f32(hi));
+    } else {
+        hi = bf16_bits(x);
+        lo = bf16_bits(x - bf16_to_f32(hi));
+    }
 }
-__device__ __forceinline__ float join2(u16 hi, u16 lo) { return bf16_to_f32(hi) + bf16_to_f32(lo); }
+__device__ __forceinline__ float join2(u16 hi, u16 lo, int f16 = 0) {
+    return f16 ? f16_to_f32(hi) + f16_to_f32(lo) : bf16_to_f32(hi) + bf16_to_f32(lo);
+}
 
 // 4 consecutive values -> two 8-byte packs (hi plane, lo plane)
-__device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo) {
+__device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo, int f16 = 0) {
     u16 h[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split2(v[i], h[i], l[i]);
+    for (int i = 0; i < 4; ++i) split2(v[i], h[i], l[i], f16);
     hi = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
     lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
-__device__ __forceinline__ void unpack4(uint2 p, float v[4]) {
-    v[0] = bf16_to_f32((u16)(p.x & 0xffff));
-    v[1] = bf16_to_f32((u16)(p.x >> 16));
-    v[2] = bf16_to_f32((u16)(p.y & 0xffff));
-    v[3] = bf16_to_f32((u16)(p.y >> 16));
+__device__ __forceinline__ void unpack4(uint2 p, float v[4], int f16 = 0) {
+    const u16 b[4] = {(u16)(p.x & 0xffff), (u16)(p.x >> 16), (u16)(p.y & 0xffff), (u16)(p.y >> 16)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = f16 ? f16_to_f32(b[i]) : bf16_to_f32(b[i]);
+}
+
+// one MFMA on 8 x 16-bit operand fragments held as raw bit patterns
+template <bool F16>
+__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

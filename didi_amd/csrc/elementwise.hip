@@ -63,31 +63,37 @@ extern "C" int didi_philox_normal(float* out, size_t n, uint64_t seed, uint64_t 
 
 // ------------------------------------------------------------------ fp32 -> split planes
 // bytes per element: 4 read + 4 written.
-__global__ void __launch_bounds__(256) split_kernel(const float* src, u16* hi, u16* lo, size_t n4) {
+__global__ void __launch_bounds__(256) split_kernel(const float* src, u16* hi, u16* lo, size_t n4, int f16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(src)[i];
         const float f[4] = {v.x, v.y, v.z, v.w};
         uint2 h, l;
-        split4(f, h, l);
+        split4(f, h, l, f16);
         reinterpret_cast<uint2*>(hi)[i] = h;
         if (lo) reinterpret_cast<uint2*>(lo)[i] = l;
     }
 }
 
-extern "C" int didi_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, size_t n, void* stream) {
+static int split_planes(const float* src, uint16_t* hi, uint16_t* lo, size_t n, int f16, void* stream) {
     DIDI_CHECK_ARG(src && hi && n % 4 == 0);
     if (n == 0) return DIDI_OK;
     const size_t n4 = n / 4;
     const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-    split_kernel<<<grid, 256, 0, as_stream(stream)>>>(src, hi, lo, n4);
+    split_kernel<<<grid, 256, 0, as_stream(stream)>>>(src, hi, lo, n4, f16);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
+}
+extern "C" int didi_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, size_t n, void* stream) {
+    return split_planes(src, hi, lo, n, 0, stream);
+}
+extern "C" int didi_split_fp16(const float* src, uint16_t* hi, uint16_t* lo, size_t n, void* stream) {
+    return split_planes(src, hi, lo, n, 1, stream);
 }
 
 // ------------------------------------------------------------------ LayerNorm tail shared by both row kernels
 template <int MAXV>
 __device__ __forceinline__ void ln_row_store(float (&v)[MAXV][4], int lane, int H, size_t row_off, const float* gamma,
-                                             const float* beta, float eps, u16* y_hi, u16* y_lo, float* y_f32) {
+                                             const float* beta, float eps, u16* y_hi, u16* y_lo, float* y_f32, int f16) {
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
@@ -123,7 +129,7 @@ __device__ __forceinline__ void ln_row_store(float (&v)[MAXV][4], int lane, int 
             if (y_f32) *reinterpret_cast<float4*>(y_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
             if (y_hi) {
                 uint2 h, l;
-                split4(y, h, l);
+                split4(y, h, l, f16);
                 *reinterpret_cast<uint2*>(y_hi + o) = h;
                 if (y_lo) *reinterpret_cast<uint2*>(y_lo + o) = l;
             }
@@ -135,7 +141,7 @@ __device__ __forceinline__ void ln_row_store(float (&v)[MAXV][4], int lane, int 
 // bytes per row: 4H read + (2H | 4H) planes [+ 4H fp32] written.
 template <int MAXV>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* x, const float* gamma, const float* beta, float eps,
-                                                        int M, int H, u16* y_hi, u16* y_lo, float* y_f32) {
+                                                        int M, int H, u16* y_hi, u16* y_lo, float* y_f32, int f16) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -151,21 +157,23 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* x, const fl
             v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
         }
     }
-    ln_row_store<MAXV>(v, lane, H, row_off, gamma, beta, eps, y_hi, y_lo, y_f32);
+    ln_row_store<MAXV>(v, lane, H, row_off, gamma, beta, eps, y_hi, y_lo, y_f32, f16);
 }
 
 extern "C" int didi_layernorm(const float* x, const float* gamma, const float* beta, float eps, int M, int H,
-                              uint16_t* y_hi, uint16_t* y_lo, float* y_f32, void* stream) {
+                              uint16_t* y_hi, uint16_t* y_lo, float* y_f32, int plane_format, void* stream) {
     DIDI_CHECK_ARG(x && gamma && beta && (y_hi || y_f32) && M >= 0 && H > 0);
+    DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
+    const int f16 = plane_format == DIDI_FMT_FP16;
     DIDI_CHECK_ARG(!(y_lo && !y_hi));
     if (H % 4 != 0 || H > 2048) return DIDI_ERR_UNSUPPORTED;
     if (M == 0) return DIDI_OK;
     const int grid = cdiv(M, 4);
     hipStream_t st = as_stream(stream);
-    if (H <= 256) layernorm_kernel<1><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32);
-    else if (H <= 768) layernorm_kernel<3><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32);
-    else if (H <= 1280) layernorm_kernel<5><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32);
-    else layernorm_kernel<8><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32);
+    if (H <= 256) layernorm_kernel<1><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32, f16);
+    else if (H <= 768) layernorm_kernel<3><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32, f16);
+    else if (H <= 1280) layernorm_kernel<5><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32, f16);
+    else layernorm_kernel<8><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32, f16);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }
@@ -230,7 +238,8 @@ __global__ void __launch_bounds__(256) step_embed_ln_kernel(didi_step_args a) {
             v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
         }
     }
-    if (a.h_hi) ln_row_store<MAXV>(v, lane, H, row_off, a.ln_gamma, a.ln_beta, a.ln_eps, a.h_hi, a.h_lo, nullptr);
+    if (a.h_hi) ln_row_store<MAXV>(v, lane, H, row_off, a.ln_gamma, a.ln_beta, a.ln_eps, a.h_hi, a.h_lo, nullptr,
+                                  a.plane_format == DIDI_FMT_FP16);
 }
 
 extern "C" int didi_step_embed_ln(const didi_step_args* a, void* stream) {
@@ -239,6 +248,7 @@ extern "C" int didi_step_embed_ln(const didi_step_args* a, void* stream) {
     if (a->mode == DIDI_STEP_EULER || a->mode == DIDI_STEP_NONE) DIDI_CHECK_ARG(a->X);
     if (a->mode == DIDI_STEP_DDPM || a->mode == DIDI_STEP_EULER) DIDI_CHECK_ARG(a->X0);
     DIDI_CHECK_ARG(a->h_hi || a->x_out || a->xin_out);
+    DIDI_CHECK_ARG(a->plane_format == DIDI_FMT_BF16 || a->plane_format == DIDI_FMT_FP16);
     if (a->h_hi) DIDI_CHECK_ARG(a->h_lo && a->time_embeds && a->pos_emb && a->tok_type0 && a->ln_gamma && a->ln_beta);
     if (a->H % 4 != 0 || a->H > 2048) return DIDI_ERR_UNSUPPORTED;
     if (a->M == 0) return DIDI_OK;

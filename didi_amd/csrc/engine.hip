@@ -99,14 +99,15 @@ extern "C" int didi_decoder_prepare_context(const didi_decoder* dec, const float
                                             void* workspace, size_t workspace_bytes, uint16_t* kv_hi, uint16_t* kv_lo,
                                             void* stream) {
     DIDI_CHECK_ARG(dec && ctx && workspace && kv_hi && dec->layers_host);
-    DIDI_CHECK_ARG(precision == DIDI_PREC_BF16 || (precision == DIDI_PREC_BF16X3 && kv_lo));
+    DIDI_CHECK_ARG(precision == DIDI_PREC_BF16 || precision == DIDI_PREC_FP16 || (precision == DIDI_PREC_BF16X3 && kv_lo));
     if (!shapes_ok(dec, B, 1, C)) return DIDI_ERR_UNSUPPORTED;
     const size_t Mc = (size_t)B * C, H = dec->H;
     const size_t plane = al256(Mc * H * 2);
     if (workspace_bytes < 2 * plane) return DIDI_ERR_WORKSPACE;
     u16* c_hi = (u16*)workspace;
     u16* c_lo = (u16*)((char*)workspace + plane);
-    TRY(didi_split_bf16(ctx, c_hi, c_lo, Mc * H, stream));
+    if (precision == DIDI_PREC_FP16) TRY(didi_split_fp16(ctx, c_hi, c_lo, Mc * H, stream));
+    else TRY(didi_split_bf16(ctx, c_hi, c_lo, Mc * H, stream));
     for (int l = 0; l < dec->L; ++l) {
         const didi_decoder_layer& ly = dec->layers_host[l];
         DIDI_CHECK_ARG(ly.ckv.N == 2 * dec->H && ly.ckv.K == dec->H);
@@ -120,7 +121,7 @@ extern "C" int didi_decoder_prepare_context(const didi_decoder* dec, const float
 extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_args* a, void* stream) {
     DIDI_CHECK_ARG(dec && a && dec->layers_host && a->workspace && a->x0_f32 && a->kv_hi && a->ctx_mask);
     const int prec = a->precision;
-    DIDI_CHECK_ARG(prec == DIDI_PREC_BF16 || (prec == DIDI_PREC_BF16X3 && a->kv_lo));
+    DIDI_CHECK_ARG(prec == DIDI_PREC_BF16 || prec == DIDI_PREC_FP16 || (prec == DIDI_PREC_BF16X3 && a->kv_lo));
     DIDI_CHECK_ARG(!(a->x0_lo && !a->x0_hi));
     if (!shapes_ok(dec, a->B, a->S, a->C)) return DIDI_ERR_UNSUPPORTED;
     if (a->S > 0 && dec->pos_emb == nullptr) return DIDI_ERR_BAD_ARG;
@@ -128,6 +129,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
     if (a->workspace_bytes < w.total) return DIDI_ERR_WORKSPACE;
     const int M = a->B * a->S, H = dec->H, I = dec->I, D = H / dec->heads;
     const bool x3 = prec == DIDI_PREC_BF16X3;
+    const int fmt = prec == DIDI_PREC_FP16 ? DIDI_FMT_FP16 : DIDI_FMT_BF16;
     const size_t Mc = (size_t)a->B * a->C;
     Prof prof{a->prof_events_host, a->prof_capacity, 0};
 
@@ -136,7 +138,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
     st.M = M; st.S = a->S; st.H = H;
     st.time_embeds = dec->time_embeds; st.pos_emb = dec->pos_emb; st.tok_type0 = dec->tok_type0;
     st.ln_gamma = dec->emb_ln_g; st.ln_beta = dec->emb_ln_b; st.ln_eps = dec->ln_eps;
-    st.h_hi = w.h_hi; st.h_lo = w.h_lo;
+    st.h_hi = w.h_hi; st.h_lo = w.h_lo; st.plane_format = fmt;
     TRY(didi_step_embed_ln(&st, stream));
 
     for (int l = 0; l < dec->L; ++l) {
@@ -154,7 +156,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.O_hi = w.att_hi; at.O_lo = x3 ? w.att_lo : nullptr; at.ldo = H;
         TRY(didi_attention(&at, stream));
         TRY(gemm(ly.attn_out, prec, M, w.att_hi, w.att_lo, H, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream, &prof));
-        TRY(didi_layernorm(w.tmp, ly.ln1_g, ly.ln1_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, stream));
+        TRY(didi_layernorm(w.tmp, ly.ln1_g, ly.ln1_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, fmt, stream));
         // --- cross-attention block (K/V hoisted: didi_decoder_prepare_context)
         u16* q_hi = w.qkv_hi;
         u16* q_lo = x3 ? w.qkv_lo : nullptr;
@@ -166,17 +168,17 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;
         TRY(didi_attention(&at, stream));
         TRY(gemm(ly.cross_out, prec, M, w.att_hi, w.att_lo, H, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream, &prof));
-        TRY(didi_layernorm(w.tmp, ly.ln2_g, ly.ln2_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, stream));
+        TRY(didi_layernorm(w.tmp, ly.ln2_g, ly.ln2_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, fmt, stream));
         // --- feed-forward block
         TRY(gemm(ly.ffn_up, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_GELU, nullptr, nullptr, 0, nullptr, w.ffn_hi,
                  x3 ? w.ffn_lo : nullptr, I, stream, &prof));
         TRY(gemm(ly.ffn_down, prec, M, w.ffn_hi, w.ffn_lo, I, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream, &prof));
         if (!last) {
-            TRY(didi_layernorm(w.tmp, ly.ln3_g, ly.ln3_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, stream));
+            TRY(didi_layernorm(w.tmp, ly.ln3_g, ly.ln3_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, fmt, stream));
         } else {
             u16* o_hi = a->x0_hi ? a->x0_hi : w.h_hi;
             u16* o_lo = a->x0_hi ? a->x0_lo : w.h_lo;
-            TRY(didi_layernorm(w.tmp, ly.ln3_g, ly.ln3_b, dec->ln_eps, M, H, o_hi, o_lo, a->x0_f32, stream));
+            TRY(didi_layernorm(w.tmp, ly.ln3_g, ly.ln3_b, dec->ln_eps, M, H, o_hi, o_lo, a->x0_f32, fmt, stream));
         }
     }
     if (a->prof_used_host) *a->prof_used_host = prof.used;
@@ -254,7 +256,10 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
         fin.X = s->x_state; fin.X0 = s->x0_f32; fin.ratio = s->c2_host[s->n_calls - 1]; fin.ce = 0.f; fin.cin = 1.0f;
         fin.x_out = s->x0_f32;
         TRY(didi_step_embed_ln(&fin, stream));
-        if (s->x0_hi) TRY(didi_split_bf16(s->x0_f32, s->x0_hi, s->x0_lo, MH, stream));
+        if (s->x0_hi) {
+            if (s->precision == DIDI_PREC_FP16) TRY(didi_split_fp16(s->x0_f32, s->x0_hi, s->x0_lo, MH, stream));
+            else TRY(didi_split_bf16(s->x0_f32, s->x0_hi, s->x0_lo, MH, stream));
+        }
     }
     if (s->ids64) {
         TRY(didi_round_argmax(s->x0_hi, s->x0_lo, dec->H, s->cls_hi, s->cls_lo, dec->H, s->B * s->S, s->V, dec->H,

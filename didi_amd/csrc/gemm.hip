@@ -43,6 +43,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 struct GemmParams {
     int M, N, K;
     int npass;
+    int f16;  // plane element format: 0 bf16, 1 fp16 (single-product mode only)
     const u16 *A_hi, *A_lo, *W_hi, *W_lo;
     int lda, ldw;
     const float* bias;
@@ -67,7 +68,7 @@ __device__ __forceinline__ void glds16(const u16* src, char* lds_dst) {
 
 // ------------------------------------------------------------------ LDS-DMA main loop
 // Accumulate one 128x128 output tile at (m0, n0).  Requires K % (NPASS == 3 ? 32 : 64) == 0.
-template <int NPASS, int NSTAGE>
+template <int NPASS, int NSTAGE, bool F16>
 __device__ __forceinline__ void tile_glds(const GemmParams& p, char* smem, int m0, int n0, f32x4 (&acc)[4][4]) {
     constexpr int BKK = NPASS == 3 ? 32 : 64;
     constexpr int ROWB = BKK * 2;              // bytes per LDS row
@@ -150,9 +151,9 @@ __device__ __forceinline__ void tile_glds(const GemmParams& p, char* smem, int m
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlf[ni], ahf[mi], acc[ni][mi], 0, 0, 0);
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whf[ni], alf[mi], acc[ni][mi], 0, 0, 0);
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whf[ni], ahf[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = mma16<F16>(wlf[ni], ahf[mi], acc[ni][mi]);
+                    acc[ni][mi] = mma16<F16>(whf[ni], alf[mi], acc[ni][mi]);
+                    acc[ni][mi] = mma16<F16>(whf[ni], ahf[mi], acc[ni][mi]);
                 }
         } else {
             const char *As = st, *Ws = st + TILEB;
@@ -169,7 +170,7 @@ __device__ __forceinline__ void tile_glds(const GemmParams& p, char* smem, int m
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = mma16<F16>(wf[ni], af[mi], acc[ni][mi]);
             }
         }
     }
@@ -177,6 +178,7 @@ __device__ __forceinline__ void tile_glds(const GemmParams& p, char* smem, int m
 }
 
 // ------------------------------------------------------------------ register-staged fallback (any K % 8 == 0)
+template <bool F16>
 __device__ __forceinline__ void tile_regstage(const GemmParams& p, char* smem, int m0, int n0, f32x4 (&acc)[4][4]) {
     constexpr int BK = 64, TILE_BYTES = 128 * 128;
     const int tid = threadIdx.x;
@@ -253,7 +255,7 @@ __device__ __forceinline__ void tile_regstage(const GemmParams& p, char* smem, i
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = mma16<F16>(wf[ni], af[mi], acc[ni][mi]);
         }
         if (more) GEMM_LSTORE(buf ^ 1);
         __syncthreads();
@@ -263,10 +265,10 @@ __device__ __forceinline__ void tile_regstage(const GemmParams& p, char* smem, i
 }
 
 // MODE 0: register-staged fallback, 1: LDS-DMA bf16, 3: LDS-DMA bf16x3
-template <int MODE, int NSTAGE>
+template <int MODE, int NSTAGE, bool F16>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m0, int n0, f32x4 (&acc)[4][4]) {
-    if constexpr (MODE == 0) tile_regstage(p, smem, m0, n0, acc);
-    else tile_glds<MODE, NSTAGE>(p, smem, m0, n0, acc);
+    if constexpr (MODE == 0) tile_regstage<F16>(p, smem, m0, n0, acc);
+    else tile_glds<MODE, NSTAGE, F16>(p, smem, m0, n0, acc);
 }
 
 // erf to <= 1.5e-7 absolute (Abramowitz & Stegun 7.1.26): rcp + exp + 5 fma instead of libm's
@@ -301,12 +303,13 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
         v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
     } else if (p.R_hi) {
         const uint2 rh = *reinterpret_cast<const uint2*>(p.R_hi + (size_t)m * p.ldr + n);
-        v0 += bf16_to_f32((u16)(rh.x & 0xffff)); v1 += bf16_to_f32((u16)(rh.x >> 16));
-        v2 += bf16_to_f32((u16)(rh.y & 0xffff)); v3 += bf16_to_f32((u16)(rh.y >> 16));
+        float r[4];
+        unpack4(rh, r, p.f16);
+        v0 += r[0]; v1 += r[1]; v2 += r[2]; v3 += r[3];
         if (p.R_lo) {
             const uint2 rl = *reinterpret_cast<const uint2*>(p.R_lo + (size_t)m * p.ldr + n);
-            v0 += bf16_to_f32((u16)(rl.x & 0xffff)); v1 += bf16_to_f32((u16)(rl.x >> 16));
-            v2 += bf16_to_f32((u16)(rl.y & 0xffff)); v3 += bf16_to_f32((u16)(rl.y >> 16));
+            unpack4(rl, r, p.f16);
+            v0 += r[0]; v1 += r[1]; v2 += r[2]; v3 += r[3];
         }
     }
     const size_t o = (size_t)m * p.ldc + n;
@@ -314,7 +317,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
     if (p.C_hi) {
         const float v[4] = {v0, v1, v2, v3};
         uint2 h, l;
-        split4(v, h, l);
+        split4(v, h, l, p.f16);
         *reinterpret_cast<uint2*>(p.C_hi + o) = h;
         if (p.C_lo) *reinterpret_cast<uint2*>(p.C_lo + o) = l;
     }
@@ -326,13 +329,13 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
 }
 
-template <int MODE, int NSTAGE>
+template <int MODE, int NSTAGE, bool F16>
 __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     f32x4 acc[4][4];
-    gemm_tile<MODE, NSTAGE>(p, smem, m0, n0, acc);
+    gemm_tile<MODE, NSTAGE, F16>(p, smem, m0, n0, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lg = lane >> 4;
@@ -376,7 +379,7 @@ template <int MT> struct BigGeom {
     static constexpr int STAGE = A_BYTES + NW * 1024;
     static constexpr int PPW = (NA + NW) / WAVES;       // pieces per wave per stage
 };
-template <int NPASS, int MT>
+template <int NPASS, int MT, bool F16>
 __global__ void __launch_bounds__(BigGeom<MT>::THREADS, 2) gemm_big_kernel(GemmParams p) {
     using G = BigGeom<MT>;
     constexpr int BKK = NPASS == 3 ? 32 : 64;
@@ -453,9 +456,9 @@ __global__ void __launch_bounds__(BigGeom<MT>::THREADS, 2) gemm_big_kernel(GemmP
             for (int ni = 0; ni < 6; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlf[ni], ahf[mi], acc[ni][mi], 0, 0, 0);
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whf[ni], alf[mi], acc[ni][mi], 0, 0, 0);
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whf[ni], ahf[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = mma16<F16>(wlf[ni], ahf[mi], acc[ni][mi]);
+                    acc[ni][mi] = mma16<F16>(whf[ni], alf[mi], acc[ni][mi]);
+                    acc[ni][mi] = mma16<F16>(whf[ni], ahf[mi], acc[ni][mi]);
                 }
         } else {
             const char *As = st, *Ws = st + W_OFF;
@@ -471,7 +474,7 @@ __global__ void __launch_bounds__(BigGeom<MT>::THREADS, 2) gemm_big_kernel(GemmP
                 for (int ni = 0; ni < 6; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = mma16<F16>(wf[ni], af[mi], acc[ni][mi]);
             }
         }
     }
@@ -490,8 +493,9 @@ __global__ void __launch_bounds__(BigGeom<MT>::THREADS, 2) gemm_big_kernel(GemmP
 
 static int fill_operands(GemmParams& p, int precision, const u16* A_hi, const u16* A_lo, const u16* W_hi, const u16* W_lo) {
     p.A_hi = A_hi; p.W_hi = W_hi;
-    if (precision == DIDI_PREC_BF16) {
+    if (precision == DIDI_PREC_BF16 || precision == DIDI_PREC_FP16) {
         p.npass = 1;
+        p.f16 = precision == DIDI_PREC_FP16;
         p.A_lo = A_hi; p.W_lo = W_hi;  // never read
         return DIDI_OK;
     }
@@ -520,20 +524,21 @@ static int gemm_big_mt() {
     static const int v = [] { const char* e = getenv("DIDI_GEMM_MT"); return e && atoi(e) == 2 ? 2 : 4; }();
     return v;
 }
-template <int NPASS, int MT>
+template <int NPASS, int MT, bool F16>
 static bool opt_in_lds() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<NPASS, MT>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<NPASS, MT, F16>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<MT>::STAGE) == hipSuccess;
 }
 static bool allow_big_lds() {  // > 64 KiB of dynamic LDS needs an opt-in, once per process
-    static const bool ok = opt_in_lds<3, 4>() && opt_in_lds<1, 4>() && opt_in_lds<3, 2>() && opt_in_lds<1, 2>();
+    static const bool ok = opt_in_lds<3, 4, false>() && opt_in_lds<1, 4, false>() && opt_in_lds<1, 4, true>() &&
+                           opt_in_lds<3, 2, false>() && opt_in_lds<1, 2, false>() && opt_in_lds<1, 2, true>();
     return ok;
 }
-template <int NPASS, int MT>
+template <int NPASS, int MT, bool F16>
 static void launch_big(GemmParams& p, hipStream_t st) {
     using G = BigGeom<MT>;
     p.tiles_m = cdiv(p.M, G::BM_);
-    gemm_big_kernel<NPASS, MT><<<p.tiles_m * p.tiles_n, G::THREADS, 2 * G::STAGE, st>>>(p);
+    gemm_big_kernel<NPASS, MT, F16><<<p.tiles_m * p.tiles_n, G::THREADS, 2 * G::STAGE, st>>>(p);
 }
 
 static inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -567,14 +572,17 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
         if (!allow_big_lds()) return DIDI_ERR_LAUNCH;
         p.tiles_n = big_tiles_n;
         const bool mt4 = gemm_big_mt() == 4;
-        if (mode == 3) { if (mt4) launch_big<3, 4>(p, st); else launch_big<3, 2>(p, st); }
-        else { if (mt4) launch_big<1, 4>(p, st); else launch_big<1, 2>(p, st); }
+        if (mode == 3) { if (mt4) launch_big<3, 4, false>(p, st); else launch_big<3, 2, false>(p, st); }
+        else if (p.f16) { if (mt4) launch_big<1, 4, true>(p, st); else launch_big<1, 2, true>(p, st); }
+        else { if (mt4) launch_big<1, 4, false>(p, st); else launch_big<1, 2, false>(p, st); }
     } else {
         p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
         const int grid = p.tiles_m * p.tiles_n;
-        if (mode == 3) gemm_kernel<3, 2><<<grid, 256, SMEM_BYTES, st>>>(p);
-        else if (mode == 1) gemm_kernel<1, 2><<<grid, 256, SMEM_BYTES, st>>>(p);
-        else gemm_kernel<0, 2><<<grid, 256, SMEM_BYTES, st>>>(p);
+        if (mode == 3) gemm_kernel<3, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
+        else if (mode == 1 && p.f16) gemm_kernel<1, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
+        else if (mode == 1) gemm_kernel<1, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
+        else if (p.f16) gemm_kernel<0, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
+        else gemm_kernel<0, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
     }
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
@@ -585,7 +593,7 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
 // (max, index) and never writes logits.  Cross-lane / cross-wave reduction once per workgroup.
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
-template <int MODE, int NSTAGE>
+template <int MODE, int NSTAGE, bool F16>
 __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_argmax_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int mt = blockIdx.x % p.tiles_m, chunk = blockIdx.x / p.tiles_m;
@@ -601,7 +609,7 @@ __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_argmax_kernel(G
     for (int tn = t_begin; tn < t_end; ++tn) {
         const int n0 = tn * BN;
         f32x4 acc[4][4];
-        gemm_tile<MODE, NSTAGE>(p, smem, m0, n0, acc);
+        gemm_tile<MODE, NSTAGE, F16>(p, smem, m0, n0, acc);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -687,9 +695,15 @@ extern "C" int didi_round_argmax(const uint16_t* X_hi, const uint16_t* X_lo, int
     hipStream_t st = as_stream(stream);
     const int grid = p.tiles_m * p.nchunks;
     switch (pick_mode(p)) {
-        case 3: gemm_argmax_kernel<3, 2><<<grid, 256, SMEM_BYTES, st>>>(p); break;
-        case 1: gemm_argmax_kernel<1, 2><<<grid, 256, SMEM_BYTES, st>>>(p); break;
-        default: gemm_argmax_kernel<0, 2><<<grid, 256, SMEM_BYTES, st>>>(p); break;
+        case 3: gemm_argmax_kernel<3, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p); break;
+        case 1:
+            if (p.f16) gemm_argmax_kernel<1, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
+            else gemm_argmax_kernel<1, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
+            break;
+        default:
+            if (p.f16) gemm_argmax_kernel<0, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
+            else gemm_argmax_kernel<0, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
+            break;
     }
     DIDI_LAUNCH_CHECK();
     argmax_reduce_kernel<<<cdiv(M, 256), 256, 0, st>>>(p.partial, M, p.nchunks, V, ids64, ids32);

@@ -24,11 +24,11 @@ from .schedule import configure_schedule
 
 
 class _Planes:
-    """A Linear's packed weights: bf16 planes [N, K] + fp32 bias."""
+    """A Linear's packed weights: split planes [N, K] (bf16, or fp16 for the "fp16" precision) + fp32 bias."""
 
-    def __init__(self, weight, bias, device):
+    def __init__(self, weight, bias, device, dtype=torch.bfloat16):
         w = weight.detach().to(device=device, dtype=torch.float32).contiguous()
-        self.hi, self.lo = ops.split(w)
+        self.hi, self.lo = ops.split(w, dtype=dtype)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.N, self.K = w.shape
 
@@ -58,7 +58,7 @@ class _Classifier:
     def __call__(self, x):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
-        hi, lo = ops.split(x2)
+        hi, lo = ops.split(x2, dtype=self.planes.hi.dtype)
         _, _, y = self.planes(hi, lo, self._owner.precision, out_f32=True, out_planes=False)
         return y.reshape(*lead, -1)
 
@@ -79,7 +79,8 @@ class DiDiSampler:
         self.emb = _Embedding(f("emb.weight"))
         self.time_embeds = _Embedding(f("time_embeds.weight"))
         cls_w = self.emb.weight if cfg.tie_weights else f("classifier.weight")
-        self._cls = _Planes(cls_w, None, dev)
+        self._pd = ops.plane_dtype(precision)  # decoder + classifier planes; the encoder side stays bf16x3
+        self._cls = _Planes(cls_w, None, dev, self._pd)
         self.classifier = _Classifier(self._cls, cls_w, self)
         if "sigmas" in sd:
             self._sigmas_host = sd["sigmas"].detach().float().cpu()
@@ -103,10 +104,10 @@ class DiDiSampler:
             def cat(block, names):
                 w = torch.cat([sd[f"{p}{block}.self.{n}.weight"] for n in names], 0)
                 b = torch.cat([sd[f"{p}{block}.self.{n}.bias"] for n in names], 0)
-                return _Planes(w, b, dev)
+                return _Planes(w, b, dev, self._pd)
 
             def lin(name):
-                return _Planes(sd[p + name + ".weight"], sd[p + name + ".bias"], dev)
+                return _Planes(sd[p + name + ".weight"], sd[p + name + ".bias"], dev, self._pd)
 
             parts = dict(
                 qkv=cat("attention", ("query", "key", "value")), attn_out=lin("attention.output.dense"),
@@ -244,8 +245,8 @@ class DiDiSampler:
                 kv_hi=torch.empty(kv_bytes, dtype=torch.uint8, device=dev),
                 kv_lo=torch.empty(kv_bytes, dtype=torch.uint8, device=dev),
                 x0=torch.empty((B, S, H), dtype=torch.float32, device=dev),
-                x0_hi=torch.empty((B * S, H), dtype=torch.bfloat16, device=dev),
-                x0_lo=torch.empty((B * S, H), dtype=torch.bfloat16, device=dev),
+                x0_hi=torch.empty((B * S, H), dtype=self._pd, device=dev),
+                x0_lo=torch.empty((B * S, H), dtype=self._pd, device=dev),
                 x_state=torch.empty((B, S, H), dtype=torch.float32, device=dev),
                 partial=torch.empty(lib.didi_round_argmax_bytes(B * S, self.cfg.vocab), dtype=torch.uint8, device=dev),
             )

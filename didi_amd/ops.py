@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import lib
 
-PRECISIONS = {"bf16": _lib.PREC_BF16, "bf16x3": _lib.PREC_BF16X3}
+PRECISIONS = {"bf16": _lib.PREC_BF16, "fp16": _lib.PREC_FP16, "bf16x3": _lib.PREC_BF16X3}
 ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "gelu": _lib.ACT_GELU, "tanh": _lib.ACT_TANH}
 
 
@@ -19,17 +19,27 @@ def _prec(p):
     return PRECISIONS[p] if isinstance(p, str) else int(p)
 
 
+def plane_dtype(precision):
+    """torch dtype of the split planes a precision works on (fp16 planes for "fp16", bf16 otherwise)."""
+    return torch.float16 if _prec(precision) == _lib.PREC_FP16 else torch.bfloat16
+
+
+def _fmt(dtype):
+    return _lib.FMT_FP16 if dtype == torch.float16 else _lib.FMT_BF16
+
+
 def _f32c(t):
     assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda, (t.dtype, t.is_contiguous(), t.device)
     return t
 
 
-def split(x, need_lo=True):
-    """fp32 tensor -> (hi, lo) bf16 planes of the same shape."""
+def split(x, need_lo=True, dtype=torch.bfloat16):
+    """fp32 tensor -> (hi, lo) planes of the same shape, bf16 (default) or fp16."""
     x = _f32c(x)
-    hi = torch.empty_like(x, dtype=torch.bfloat16)
-    lo = torch.empty_like(x, dtype=torch.bfloat16) if need_lo else None
-    _lib.check(lib.didi_split_bf16(x.data_ptr(), hi.data_ptr(), _lib.ptr(lo), x.numel(), _lib.current_stream()), "split")
+    hi = torch.empty_like(x, dtype=dtype)
+    lo = torch.empty_like(x, dtype=dtype) if need_lo else None
+    fn = lib.didi_split_fp16 if dtype == torch.float16 else lib.didi_split_bf16
+    _lib.check(fn(x.data_ptr(), hi.data_ptr(), _lib.ptr(lo), x.numel(), _lib.current_stream()), "split")
     return hi, lo
 
 
@@ -55,14 +65,14 @@ def embed_gather(ids, table, scale=1.0, pos=None):
     return out
 
 
-def layernorm(x, gamma, beta, eps, planes=True, need_lo=True, f32=False):
+def layernorm(x, gamma, beta, eps, planes=True, need_lo=True, f32=False, dtype=torch.bfloat16):
     x = _f32c(x)
     M, H = x.numel() // x.shape[-1], x.shape[-1]
-    hi = torch.empty_like(x, dtype=torch.bfloat16) if planes else None
-    lo = torch.empty_like(x, dtype=torch.bfloat16) if planes and need_lo else None
+    hi = torch.empty_like(x, dtype=dtype) if planes else None
+    lo = torch.empty_like(x, dtype=dtype) if planes and need_lo else None
     y = torch.empty_like(x) if f32 else None
     _lib.check(lib.didi_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, M, H, _lib.ptr(hi), _lib.ptr(lo),
-                                  _lib.ptr(y), _lib.current_stream()), "layernorm")
+                                  _lib.ptr(y), _fmt(dtype), _lib.current_stream()), "layernorm")
     return hi, lo, y
 
 
@@ -82,8 +92,10 @@ def gemm(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, precision="bf16x3", residu
     if residual_planes is not None:
         g.R_hi, g.R_lo, g.ldr = residual_planes[0].data_ptr(), _lib.ptr(residual_planes[1]), residual_planes[0].stride(0)
     c_f32 = torch.empty((M, N), dtype=torch.float32, device=dev) if out_f32 else None
-    c_hi = torch.empty((M, N), dtype=torch.bfloat16, device=dev) if out_planes else None
-    c_lo = torch.empty((M, N), dtype=torch.bfloat16, device=dev) if out_planes and out_lo else None
+    pd = plane_dtype(precision)
+    assert a_hi.dtype == pd and w_hi.dtype == pd, f"{precision} operands must be {pd} planes"
+    c_hi = torch.empty((M, N), dtype=pd, device=dev) if out_planes else None
+    c_lo = torch.empty((M, N), dtype=pd, device=dev) if out_planes and out_lo else None
     g.C_f32, g.C_hi, g.C_lo, g.ldc = _lib.ptr(c_f32), _lib.ptr(c_hi), _lib.ptr(c_lo), N
     _lib.check(lib.didi_gemm_bf16(C.byref(g), _lib.current_stream()), "gemm")
     return c_hi, c_lo, c_f32
@@ -101,7 +113,8 @@ def attention(q, k, v, heads, causal=False, key_mask=None, precision="bf16x3"):
     a.V_hi, a.V_lo, a.ldv = v[0].data_ptr(), _lib.ptr(v[1]), v[0].stride(1)
     for t, s in ((q[0], Sq), (k[0], Sk), (v[0], Sk)):
         assert t.stride(0) == s * t.stride(1) and t.stride(2) == 1, "planes must be [B*S, ld] row-major"
-    o_hi = torch.empty((B, Sq, HD), dtype=torch.bfloat16, device=q[0].device)
+    assert q[0].dtype == plane_dtype(precision), "operand planes must match the precision's format"
+    o_hi = torch.empty((B, Sq, HD), dtype=q[0].dtype, device=q[0].device)
     o_lo = torch.empty_like(o_hi) if a.precision == _lib.PREC_BF16X3 else None
     a.O_hi, a.O_lo, a.ldo = o_hi.data_ptr(), _lib.ptr(o_lo), HD
     _lib.check(lib.didi_attention(C.byref(a), _lib.current_stream()), "attention")
@@ -140,4 +153,5 @@ def step_embed_ln(mode, M, S, H, *, X=None, X0=None, E=None, cx0=0.0, ce=0.0, ra
     a.pos_emb, a.tok_type0, a.ln_gamma, a.ln_beta, a.ln_eps = (_lib.ptr(pos_emb), _lib.ptr(tok_type0), _lib.ptr(ln_gamma),
                                                                _lib.ptr(ln_beta), ln_eps)
     a.h_hi, a.h_lo = _lib.ptr(h_hi), _lib.ptr(h_lo)
+    a.plane_format = _fmt(h_hi.dtype) if h_hi is not None else _lib.FMT_BF16
     _lib.check(lib.didi_step_embed_ln(C.byref(a), _lib.current_stream()), "step_embed_ln")

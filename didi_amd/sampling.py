@@ -100,7 +100,7 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
     if isinstance(noise, str):
         _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace)
         if want_ids:
-            x0_hi, x0_lo = ops.split(b["x0"].view(B * S, H))
+            x0_hi, x0_lo = ops.split(b["x0"].view(B * S, H), dtype=model._pd)
             ids = ops.round_argmax(x0_hi, x0_lo if model.precision == "bf16x3" else None, model._cls.hi, model._cls.lo,
                                    model.precision).view(B, S)
     else:

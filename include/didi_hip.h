@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DIDI_ABI_VERSION 1
+#define DIDI_ABI_VERSION 2
 
 enum {
     DIDI_OK = 0,
@@ -38,7 +38,13 @@ enum {
     DIDI_ERR_WORKSPACE = -4    /* workspace too small */
 };
 
-enum { DIDI_PREC_BF16 = 1, DIDI_PREC_BF16X3 = 3 }; /* = MFMA passes per product */
+/* Operand precision of GEMMs and attention.  BF16 / BF16X3: bf16 planes, 1 / 3 MFMA products.
+ * FP16: fp16 planes (hi = RNE fp16 of the value, lo = fp16 of the remainder), ONE product on the hi
+ * planes -- 8x finer operand rounding than BF16 at the same MFMA cost; lo planes are only read where
+ * a value is re-joined (residual adds).  Planes written by a call take the format of its precision
+ * (fp16 for DIDI_PREC_FP16, bf16 otherwise). */
+enum { DIDI_PREC_BF16 = 1, DIDI_PREC_FP16 = 2, DIDI_PREC_BF16X3 = 3 };
+enum { DIDI_FMT_BF16 = 0, DIDI_FMT_FP16 = 1 }; /* element format of split planes */
 
 /* ABI version / error text (no reference counterpart). */
 int didi_version(void);
@@ -49,6 +55,8 @@ const char* didi_error_string(int code);
 /* fp32 [n] -> split planes.  Used once per weight matrix at load time and for the encoder
  * context.  (No reference counterpart: the reference keeps fp32 everywhere.)  n % 4 == 0. */
 int didi_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, size_t n, void* stream);
+/* the same into fp16 planes (DIDI_PREC_FP16 operands) */
+int didi_split_fp16(const float* src, uint16_t* hi, uint16_t* lo, size_t n, void* stream);
 
 /* Standard-normal noise, Philox4x32-10 + Box-Muller, counter-based: element i of the call with
  * (seed, offset) depends only on (seed, offset + i/4).  Replaces `noise.normal_(0, 1)`
@@ -93,6 +101,7 @@ typedef struct didi_step_args {
     float ln_eps;
     uint16_t* h_hi; /* [M,H] or NULL to skip the embedding/LayerNorm part */
     uint16_t* h_lo; /* [M,H] */
+    int plane_format; /* DIDI_FMT_* of h_hi / h_lo */
 } didi_step_args;
 int didi_step_embed_ln(const didi_step_args* a, void* stream);
 
@@ -108,9 +117,10 @@ int didi_embed_gather(const int64_t* ids, const float* table, float scale, const
  * variance, eps inside the sqrt).  Replaces BertSelfOutput/BertOutput.LayerNorm
  * (HF:models/bert/modeling_bert.py:292,350) -- the dense+bias+residual part is the GEMM epilogue --
  * and the encoder's pre-LN norms.  Outputs: split planes (y_hi required unless y_f32 given;
- * y_lo may be NULL) and/or fp32 y_f32.  H % 4 == 0, H <= 2048. */
+ * y_lo may be NULL; element format plane_format = DIDI_FMT_*) and/or fp32 y_f32.
+ * H % 4 == 0, H <= 2048. */
 int didi_layernorm(const float* x, const float* gamma, const float* beta, float eps, int M, int H,
-                   uint16_t* y_hi, uint16_t* y_lo, float* y_f32, void* stream);
+                   uint16_t* y_hi, uint16_t* y_lo, float* y_f32, int plane_format, void* stream);
 
 /* ---------------------------------------------------------------- GEMM (MFMA bf16) */
 
@@ -119,7 +129,7 @@ int didi_layernorm(const float* x, const float* gamma, const float* beta, float 
  * contiguous), pre-split into planes.  Replaces every nn.Linear on the path:
  * Bert query/key/value/dense (HF:models/bert/modeling_bert.py:175-177,244,253-254,290,335,348),
  * the adapter (src/diffusion/model.py:123), `classifier` (src/sampling.py:64,82).
- *   precision : DIDI_PREC_BF16 (A_hi*W_hi) or DIDI_PREC_BF16X3 (+ A_hi*W_lo + A_lo*W_hi)
+ *   precision : DIDI_PREC_BF16 / DIDI_PREC_FP16 (A_hi*W_hi) or DIDI_PREC_BF16X3 (+ A_hi*W_lo + A_lo*W_hi)
  *   epilogue  : v = acc (+ bias[n]) ; v = act(v) ; v += residual[m,n]
  *               act: 0 none, 1 exact-erf GELU (hidden_act="gelu"), 2 tanh
  *               residual: fp32 [M, ldr] or split planes (hi+lo), or none

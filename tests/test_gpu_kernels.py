@@ -3,6 +3,7 @@
 Tolerances (stated per test):
   * bf16 mode   : compared with the SAME bf16-rounded operands multiplied in fp64 -> only the
                   fp32 accumulation order differs: rel-L2 <= 2e-5.
+  * fp16 mode   : the same with fp16-rounded operands (one product on fp16 planes).
   * bf16x3 mode : compared with the un-rounded fp32 operands in fp64: rel-L2 <= 3e-5 (the split
                   representation carries ~16 mantissa bits; the lo*lo term is dropped).
   * integer outputs (argmax ids, eos lengths, raw Philox stream): exact.
@@ -26,6 +27,10 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
+PD = {"bf16": torch.bfloat16, "fp16": torch.float16, "bf16x3": torch.bfloat16}  # plane dtype per precision
+ALL_PREC = ["bf16", "fp16", "bf16x3"]
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
@@ -40,6 +45,17 @@ def test_split_planes(ops):
     back = ops.join(hi, lo).cpu()
     err = (back - x).abs() / x.abs().clamp_min(1e-20)
     assert err.max().item() <= 2.0**-15, err.max().item()
+
+
+def test_split_planes_fp16(ops):
+    x = rnd(1000, 128, seed=1, scale=3.0)
+    x[0, :4] = torch.tensor([0.0, -0.0, 1e-30, 65504.0])
+    hi, lo = ops.split(x.cuda(), dtype=torch.float16)
+    assert hi.dtype == torch.float16 and torch.equal(hi.cpu(), x.to(torch.float16)), "hi plane must be RNE fp16 of the value"
+    back = ops.join(hi, lo).cpu()
+    # |x| < ~0.1 puts the remainder into fp16 subnormals (quantum 2^-24): absolute error <= 2^-25 there,
+    # relative 2^-22 above
+    assert ((back - x).abs() <= torch.maximum(x.abs() * 2.0**-21, torch.tensor(2.0**-24))).all()
 
 
 # ------------------------------------------------------------------ philox
@@ -66,6 +82,8 @@ def test_layernorm(ops, M, H):
     assert rel_l2(y, want) <= 1e-6
     assert rel_l2(ops.join(hi, lo), want) <= 2e-5
     assert torch.equal(hi.cpu(), y.cpu().to(torch.bfloat16))
+    hi, lo, y = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-12, f32=True, dtype=torch.float16)
+    assert torch.equal(hi.cpu(), y.cpu().to(torch.float16)) and rel_l2(ops.join(hi, lo), want) <= 2e-6
 
 
 def test_embed_gather(ops):
@@ -104,7 +122,7 @@ def test_step_embed_ln_modes(ops, H):
             want = torch.nn.functional.layer_norm(pre, (H,), g.double(), b.double(), 1e-12)
             x_out = torch.empty(M, H, device="cuda")
             xin = torch.empty(M, H, device="cuda")
-            h_hi = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
+            h_hi = torch.empty(M, H, dtype=torch.float16 if per_row_t else torch.bfloat16, device="cuda")
             h_lo = torch.empty_like(h_hi)
             ops.step_embed_ln(mode, M, S, H, X=dev(X), X0=dev(X0), E=dev(E), x_out=x_out, xin_out=xin,
                               time_embeds=dev(temb), t=5, time_idx=dev(tidx) if per_row_t else None, pos_emb=dev(pos),
@@ -142,13 +160,13 @@ def _gemm_ref(a, w, bias, act, resid):
 
 @pytest.mark.parametrize("M,N,K", [(184, 384, 128), (1, 128, 128), (130, 600, 128), (257, 8008, 128), (64, 288, 96),
                                    (300, 768, 768), (200, 768, 3072), (129, 2304, 768), (50, 768, 1280)])
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", ALL_PREC)
 def test_gemm_plain(ops, M, N, K, precision):
     a, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
-    a_hi, a_lo = ops.split(a.cuda())
-    w_hi, w_lo = ops.split(w.cuda())
+    a_hi, a_lo = ops.split(a.cuda(), dtype=PD[precision])
+    w_hi, w_lo = ops.split(w.cuda(), dtype=PD[precision])
     c_hi, c_lo, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), precision=precision, out_f32=True)
-    if precision == "bf16":
+    if precision != "bf16x3":
         want = _gemm_ref(a_hi.cpu().float(), w_hi.cpu().float(), bias, None, None)
         tol = 2e-5
     else:
@@ -157,7 +175,7 @@ def test_gemm_plain(ops, M, N, K, precision):
     assert rel_l2(c, want) <= tol, rel_l2(c, want)
     assert (c.cpu().double() - want).abs().max().item() <= 50 * tol * want.abs().max().item()
     assert rel_l2(ops.join(c_hi, c_lo), c) <= 2e-5
-    assert torch.equal(c_hi.cpu(), c.cpu().to(torch.bfloat16))
+    assert torch.equal(c_hi.cpu(), c.cpu().to(PD[precision]))
 
 
 @pytest.mark.parametrize("act", [None, "gelu", "tanh"])
@@ -183,13 +201,13 @@ def test_gemm_epilogues(ops, act, resid):
 
 
 @pytest.mark.parametrize("M,N,K", [(2304, 768, 768), (2100, 2304, 768), (2048, 8008, 768), (2050, 576, 3072), (4096, 3072, 128)])
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", ALL_PREC)
 def test_gemm_big_tile(ops, M, N, K, precision):
     """M >= 2048 selects the 256x192 8-wave tile (M and N tails, all epilogue branches)."""
     a, w, bias, r = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=0.05), rnd(N, seed=23), rnd(M, N, seed=24)
-    a_hi, a_lo = ops.split(a.cuda())
-    w_hi, w_lo = ops.split(w.cuda())
-    rp = ops.split(r.cuda())
+    a_hi, a_lo = ops.split(a.cuda(), dtype=PD[precision])
+    w_hi, w_lo = ops.split(w.cuda(), dtype=PD[precision])
+    rp = ops.split(r.cuda(), dtype=PD[precision])
     x3 = precision == "bf16x3"
     ar, wr = (a, w) if x3 else (a_hi.cpu().float(), w_hi.cpu().float())
     tol = 3e-5 if x3 else 2e-5
@@ -197,7 +215,7 @@ def test_gemm_big_tile(ops, M, N, K, precision):
     want = _gemm_ref(ar, wr, bias, None, None)
     assert rel_l2(c, want) <= tol, rel_l2(c, want)
     assert (c.cpu().double() - want).abs().max().item() <= 50 * tol * want.abs().max().item()
-    assert torch.equal(c_hi.cpu(), c.cpu().to(torch.bfloat16))
+    assert torch.equal(c_hi.cpu(), c.cpu().to(PD[precision]))
     assert rel_l2(ops.join(c_hi, c_lo), c) <= 2e-5
     _, _, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), act="gelu", precision=precision, residual_planes=rp,
                        out_f32=True, out_planes=False)
@@ -209,9 +227,9 @@ def test_gemm_big_tile_identity_asymmetric(ops):
     a = torch.zeros(M, K)
     a[torch.arange(M), torch.arange(M) % K] = 1.0  # row m selects column m % K of W^T
     w = (torch.arange(768 * K, dtype=torch.float32).reshape(768, K) % 251) - 125  # exact in bf16
-    a_hi, a_lo = ops.split(a.cuda())
-    w_hi, w_lo = ops.split(w.cuda())
-    for precision in ("bf16", "bf16x3"):
+    for precision in ALL_PREC:
+        a_hi, a_lo = ops.split(a.cuda(), dtype=PD[precision])
+        w_hi, w_lo = ops.split(w.cuda(), dtype=PD[precision])
         _, _, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, precision=precision, out_f32=True, out_planes=False)
         assert torch.equal(c.cpu(), w.t()[torch.arange(M) % K].contiguous())
 
@@ -238,13 +256,13 @@ def test_gemm_rejects_bad_shapes(ops):
 
 # ------------------------------------------------------------------ rounding (classifier + argmax)
 @pytest.mark.parametrize("M,V,K", [(184, 8008, 128), (77, 600, 128), (300, 8008, 768), (5, 130, 64)])
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", ALL_PREC)
 def test_round_argmax(ops, M, V, K, precision):
     x, w = rnd(M, K, seed=11), rnd(V, K, seed=12, scale=0.02)
-    x_hi, x_lo = ops.split(x.cuda())
-    w_hi, w_lo = ops.split(w.cuda())
+    x_hi, x_lo = ops.split(x.cuda(), dtype=PD[precision])
+    w_hi, w_lo = ops.split(w.cuda(), dtype=PD[precision])
     ids = ops.round_argmax(x_hi, x_lo, w_hi, w_lo, precision).cpu()
-    if precision == "bf16":
+    if precision != "bf16x3":
         logits = x_hi.cpu().double() @ w_hi.cpu().double().t()
     else:
         logits = x.double() @ w.double().t()
@@ -263,9 +281,9 @@ def test_round_argmax_first_index_wins_ties(ops):
     w[650] = w[3]
     w[400] = w[3]
     x[:] = w[3] * 50  # rows aligned with w[3]: rows 3, 400, 650 of W give bitwise-identical maxima
-    x_hi, x_lo = ops.split(x.cuda())
-    w_hi, w_lo = ops.split(w.cuda())
-    for precision in ("bf16", "bf16x3"):
+    for precision in ALL_PREC:
+        x_hi, x_lo = ops.split(x.cuda(), dtype=PD[precision])
+        w_hi, w_lo = ops.split(w.cuda(), dtype=PD[precision])
         ids = ops.round_argmax(x_hi, x_lo, w_hi, w_lo, precision).cpu()
         assert (ids == 3).all(), ids
 
@@ -304,7 +322,7 @@ def _attn_ref(q, k, v, heads, causal, key_mask):
     (2, 4, 12, 12, 24, False, True), (1, 32, 24, 24, 40, False, True), (2, 2, 1, 1, 64, True, False),
     (1, 2, 96, 96, 64, True, False),
 ])
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", ALL_PREC)
 def test_attention(ops, B, heads, Sq, Sk, d, causal, masked, precision):
     HD = heads * d
     qkv = rnd(B, max(Sq, Sk), 3 * HD, seed=Sq * 7 + d, scale=1.5)
@@ -314,7 +332,7 @@ def test_attention(ops, B, heads, Sq, Sk, d, causal, masked, precision):
         lens = torch.tensor([Sk, max(1, Sk // 3), 2, 1][:B])
         key_mask = (torch.arange(Sk)[None] < lens[:, None]).int()
     x3 = precision == "bf16x3"
-    hi, lo = ops.split(qkv.cuda(), need_lo=x3)
+    hi, lo = ops.split(qkv.cuda(), need_lo=x3, dtype=PD[precision])
 
     def view(t, s, c0):
         return None if t is None else t[:, :s, c0:c0 + HD]
@@ -333,9 +351,9 @@ def test_attention(ops, B, heads, Sq, Sk, d, causal, masked, precision):
         want = _attn_ref(q, k, v, heads, causal, key_mask)
         got, tol = ops.join(o_hi, o_lo), 5e-5
     else:
-        f = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+        f = lambda t: t.to(PD[precision]).float()  # noqa: E731
         want = _attn_ref(f(q), f(k), f(v), heads, causal, key_mask)
-        got, tol = o_hi.float(), 1.2e-2  # P and O are additionally rounded to bf16
+        got, tol = o_hi.float(), (1.2e-2 if precision == "bf16" else 1.5e-3)  # P and O are additionally rounded to 16 bits
     assert rel_l2(got, want) <= tol, rel_l2(got, want)
     assert torch.isfinite(got).all()
 

@@ -3,6 +3,8 @@
 Bars (BASELINE.json north_star): with identical weights and identical injected noise,
   * bf16x3 ("fp32-class") : every denoiser input x_t rel-L2 <= 1e-4, logits rel-L2 <= 1e-4,
                             token ids identical on >= 99.9 % of positions;
+  * fp16                  : one product on fp16 planes: x_t rel-L2 <= 1e-3 (BASELINE.md bar "1e-3 in bf16";
+                            measured ~1.2e-4), logits <= 2e-3, token ids >= 99.9 % -- the same id bar as bf16x3;
   * bf16                  : x_t rel-L2 <= 1e-2 (north_star quotes 1e-3 "e.g."; measured values are
                             printed), ids reported, >= 97 % required on random-init weights whose
                             top-2 logit gaps are O(1e-1) (DESIGN.md "Precision").
@@ -37,7 +39,7 @@ TINY_CASES = ["tiny_ddpm_f1", "tiny_ddpm_f3_len8", "tiny_euler_f2", "tiny_euler_
 
 
 @pytest.mark.parametrize("name", TINY_CASES + ["tiny_bertenc_ddpm_f2"])
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
 def test_golden_cases(name, precision):
     from didi_amd.sampling import sample
 
@@ -61,6 +63,9 @@ def test_golden_cases(name, precision):
     if precision == "bf16x3":
         assert worst <= 1e-4 and lerr <= 1e-4
         assert match >= 0.999
+    elif precision == "fp16":
+        assert worst <= 1e-3 and lerr <= 2e-3
+        assert match >= 0.999
     else:
         assert worst <= 1e-2 and lerr <= 2e-2
         assert match >= 0.97
@@ -70,7 +75,7 @@ def test_golden_cases(name, precision):
     assert torch.equal(ids.cpu()[clear], logits.argmax(-1).cpu()[clear])
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
 def test_config1_against_reference_fixture(precision):
     """BASELINE config 1 (V=8008, T=50, B=8, C=24): expected outputs come from the reference run."""
     from didi_amd.sampling import sample
@@ -87,8 +92,8 @@ def test_config1_against_reference_fixture(precision):
     worst = max(rel_l2(trace[i], t[f"xt.{i}"]) for i in meta["kept_calls"])
     match = (ids.cpu() == t["out.ids"]).float().mean().item()
     print(f"\n[config1 {precision}] max x_t rel-L2 {worst:.3e}  id match {match:.4f}")
-    assert worst <= (1e-4 if precision == "bf16x3" else 1e-2)
-    assert match >= (0.999 if precision == "bf16x3" else 0.97)
+    assert worst <= {"bf16x3": 1e-4, "fp16": 1e-3, "bf16": 1e-2}[precision]
+    assert match >= (0.97 if precision == "bf16" else 0.999)
     assert lengths.cpu().tolist() == [ids.shape[1]] * ids.shape[0]  # no tokenizer -> no eos -> full rows
 
 
@@ -188,6 +193,13 @@ def test_full_size_decoder_properties():
     mb = _model(sd, cfg, "bf16")
     out_b, _ = mb(encoder_attention_mask=mask[:2].cuda(), decoder_inputs_embeds=x_t[:2].cuda(), time_ids=tids[:2].cuda(), context=ctx2)
     e_b = rel_l2(out_b, want)
-    print(f"\n[full-size forward] context rel-L2 {e_ctx:.3e}  x0_hat rel-L2 bf16x3 {e_out:.3e}  bf16 {e_b:.3e}")
+    del mb
+    mh = _model(sd, cfg, "fp16")
+    out_h, _ = mh(encoder_attention_mask=mask[:2].cuda(), decoder_inputs_embeds=x_t[:2].cuda(), time_ids=tids[:2].cuda(), context=ctx2)
+    e_h = rel_l2(out_h, want)
+    out_h40, _ = mh(encoder_attention_mask=mask.cuda(), decoder_inputs_embeds=x_t.cuda(), time_ids=tids.cuda(), context=ctx)
+    e_h40 = rel_l2(out_h40[:2], want)  # 256x192 tile path
+    print(f"\n[full-size forward] context rel-L2 {e_ctx:.3e}  x0_hat rel-L2 bf16x3 {e_out:.3e}  fp16 {e_h:.3e} / {e_h40:.3e}  bf16 {e_b:.3e}")
     assert e_ctx <= 1e-4 and e_out <= 1e-4
+    assert e_h <= 2e-3 and e_h40 <= 2e-3
     assert e_b <= 2e-2

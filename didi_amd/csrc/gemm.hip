@@ -323,6 +323,54 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
     }
 }
 
+// the same for 8 consecutive output columns: 16-byte plane stores / loads instead of 8-byte ones (the
+// epilogue is store-issue bound: half the instructions, twice the contiguous bytes per row)
+__device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32x4 lo4, f32x4 hi4) {
+    float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (p.act != DIDI_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = act_apply(v[i], p.act);
+    }
+    if (p.R_f32) {
+        const float4 r0 = *reinterpret_cast<const float4*>(p.R_f32 + (size_t)m * p.ldr + n);
+        const float4 r1 = *reinterpret_cast<const float4*>(p.R_f32 + (size_t)m * p.ldr + n + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    } else if (p.R_hi) {
+        const uint4 rh = *reinterpret_cast<const uint4*>(p.R_hi + (size_t)m * p.ldr + n);
+        float r[4];
+        unpack4(make_uint2(rh.x, rh.y), r, p.f16);
+        v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+        unpack4(make_uint2(rh.z, rh.w), r, p.f16);
+        v[4] += r[0]; v[5] += r[1]; v[6] += r[2]; v[7] += r[3];
+        if (p.R_lo) {
+            const uint4 rl = *reinterpret_cast<const uint4*>(p.R_lo + (size_t)m * p.ldr + n);
+            unpack4(make_uint2(rl.x, rl.y), r, p.f16);
+            v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+            unpack4(make_uint2(rl.z, rl.w), r, p.f16);
+            v[4] += r[0]; v[5] += r[1]; v[6] += r[2]; v[7] += r[3];
+        }
+    }
+    const size_t o = (size_t)m * p.ldc + n;
+    if (p.C_f32) {
+        *reinterpret_cast<float4*>(p.C_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p.C_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    if (p.C_hi) {
+        uint2 h0, l0, h1, l1;
+        split4(v, h0, l0, p.f16);
+        split4(v + 4, h1, l1, p.f16);
+        *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        if (p.C_lo) *reinterpret_cast<uint4*>(p.C_lo + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
 // bijective XCD remap of a 1-D grid (cdna_hip_programming.md, "XCD swizzle must be bijective")
 __device__ __forceinline__ int xcd_remap(int id, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = id & 7;
@@ -491,6 +539,181 @@ __global__ void __launch_bounds__(BigGeom<MT>::THREADS, 2) gemm_big_kernel(GemmP
     }
 }
 
+// ------------------------------------------------------------------ big tile, staggered wave groups
+// Same 256x192 tile, stage layout, swizzles and accumulation order as gemm_big_kernel<*, 4>, with the
+// K-loop rescheduled (tools/gemm_lab.hip / gemm_lab1.hip hold the measurements).  s_memtime stamps of
+// the in-phase loop showed where a K-tile's cycles went: all 8 waves issue their LDS-DMA at once and
+// the CU's address path takes ~16 cycles per 1-KiB piece, so 56 pieces stall every wave for ~490
+// cycles with the MFMA pipe idle, then all waves wait for their fragment reads together.  Here waves
+// 0-3 (group X) and 4-7 (group Y; waves w and w+4 share a SIMD) run half a K-tile apart, so one
+// group's fragment reads and DMA issue sit under the other group's MFMAs.  Slots of iteration i
+// (each closed by a barrier every wave executes):
+//   A_i : X reads tile i, then issues the weight pieces W(i+1)   | Y multiplies tile i-1
+//   B1_i: X multiplies tile i (first third)                      | Y reads tile i   -> buffer i&1 is free
+//   B2_i: X multiplies tile i (rest), waits for W(i+1)           | Y issues the activation pieces A(i+2)
+//                                                                   into buffer i&1, waits for A(i+1)
+// The activation pieces (the ones that can miss L2) get 1.5 K-tiles of flight, the weight pieces
+// (L2 hits) one; every DMA wait is a counted vmcnt followed by a barrier before the first read.
+template <int NPASS, bool F16>
+__global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
+    using G = BigGeom<4>;
+    constexpr int BKK = NPASS == 3 ? 32 : 64;
+    constexpr int CPR = BKK * 2 / 16, RPI = 64 / CPR;   // 16-byte chunks per LDS row, rows per DMA piece
+    constexpr int W_OFF = G::A_BYTES, LO_A = G::A_BYTES / 2, LO_W = 12288, STAGE = G::STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * BBN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int grp = wave >> 2, w4 = wave & 3;
+
+    f32x4 acc[6][4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // group Y: activation pieces q = w4 + 4j (j < 8) of 32; group X: weight pieces q = w4 + 4j (j < 6) of 24
+    const u16* src[8];
+    int qoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = w4 + 4 * (grp ? j : (j < 6 ? j : 5));
+        const u16* base;
+        int row;
+        if (NPASS == 3) {
+            if (grp) { base = q < 16 ? p.A_hi : p.A_lo; row = (q & 15) * RPI; }
+            else { base = q < 12 ? p.W_hi : p.W_lo; row = (q < 12 ? q : q - 12) * RPI; }
+        } else {
+            base = grp ? p.A_hi : p.W_hi; row = q * RPI;
+        }
+        row += lane / CPR;
+        const int slot = lane % CPR;
+        const int g = NPASS == 3 ? (slot ^ ((0 - (row >> 2)) & 3)) : (slot ^ (row & 7));
+        // LDS weight row r' = 96*wn + 16*ni + rho holds output column 96*wn + 32*(ni>>1) + 8*(rho>>2) + 4*(ni&1) + (rho&3):
+        // accumulator tiles 2k and 2k+1 then give every lane 8 CONSECUTIVE columns (epilogue8)
+        const int wn_ = row / 96, rr_ = row % 96, ni_ = rr_ >> 4, rho_ = rr_ & 15;
+        const int col = wn_ * 96 + 32 * (ni_ >> 1) + 8 * (rho_ >> 2) + 4 * (ni_ & 1) + (rho_ & 3);
+        src[j] = base + (size_t)(grp ? min(m0 + row, p.M - 1) * (size_t)p.lda : min(n0 + col, p.N - 1) * (size_t)p.ldw) + g * 8;
+        qoff[j] = (grp ? 0 : W_OFF) + q * 1024;
+    }
+    const int nt = p.K / BKK;
+#define PP_ISSUE(T, BUF, N)                                                                        \
+    do {                                                                                           \
+        char* st_ = smem + (BUF) * STAGE;                                                          \
+        _Pragma("unroll") for (int j = 0; j < (N); ++j) glds16(src[j] + (T) * BKK, st_ + qoff[j]); \
+    } while (0)
+
+    // fragments: NPASS 1: fw[ks*6 + ni], fa[ks*4 + mi]; NPASS 3: fw[ni] hi, fw[6 + ni] lo, fa[mi] hi, fa[4 + mi] lo
+    bf16x8 fw[12], fa[8];
+#define PP_READ(ST)                                                                                        \
+    do {                                                                                                   \
+        if constexpr (NPASS == 3) {                                                                        \
+            _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                \
+                const int wo = swz64(wn * 96 + i * 16 + lr, lg);                                           \
+                fw[i] = *reinterpret_cast<const bf16x8*>((ST) + W_OFF + wo);                               \
+                fw[6 + i] = *reinterpret_cast<const bf16x8*>((ST) + W_OFF + LO_W + wo);                    \
+            }                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+                const int ao = swz64(wm * 64 + i * 16 + lr, lg);                                           \
+                fa[i] = *reinterpret_cast<const bf16x8*>((ST) + ao);                                       \
+                fa[4 + i] = *reinterpret_cast<const bf16x8*>((ST) + LO_A + ao);                            \
+            }                                                                                              \
+        } else {                                                                                           \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                             \
+                _Pragma("unroll") for (int i = 0; i < 6; ++i)                                              \
+                    fw[ks * 6 + i] = *reinterpret_cast<const bf16x8*>((ST) + W_OFF + swz128(wn * 96 + i * 16 + lr, ks * 4 + lg)); \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+                    fa[ks * 4 + i] = *reinterpret_cast<const bf16x8*>((ST) + swz128(wm * 64 + i * 16 + lr, ks * 4 + lg)); \
+            }                                                                                              \
+        }                                                                                                  \
+    } while (0)
+    // PART 0: what runs in slot B1, PART 1: the rest, PART 2: everything
+#define PP_MFMA(PART)                                                                                      \
+    do {                                                                                                   \
+        if constexpr (NPASS == 3) {                                                                        \
+            _Pragma("unroll") for (int ni = ((PART) == 1 ? 2 : 0); ni < ((PART) == 0 ? 2 : 6); ++ni)       \
+                _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                         \
+                    acc[ni][mi] = mma16<false>(fw[6 + ni], fa[mi], acc[ni][mi]);                           \
+                    acc[ni][mi] = mma16<false>(fw[ni], fa[4 + mi], acc[ni][mi]);                           \
+                    acc[ni][mi] = mma16<false>(fw[ni], fa[mi], acc[ni][mi]);                               \
+                }                                                                                          \
+        } else {                                                                                           \
+            _Pragma("unroll") for (int ni = ((PART) == 1 ? 4 : 0); ni < ((PART) == 0 ? 4 : 6); ++ni)       \
+                _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                           \
+                    acc[ni][mi] = mma16<F16>(fw[ni], fa[mi], acc[ni][mi]);                                 \
+            if constexpr ((PART) != 0) {                                                                   \
+                _Pragma("unroll") for (int ni = 0; ni < 6; ++ni)                                           \
+                    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                       \
+                        acc[ni][mi] = mma16<F16>(fw[6 + ni], fa[4 + mi], acc[ni][mi]);                     \
+            }                                                                                              \
+        }                                                                                                  \
+    } while (0)
+
+    if (grp == 0) { PP_ISSUE(0, 0, 6); if (nt > 1) PP_ISSUE(1, 1, 6); }
+    else { PP_ISSUE(0, 0, 8); if (nt > 1) PP_ISSUE(1, 1, 8); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 0) {
+        for (int i = 0; i < nt; ++i) {
+            const char* st = smem + (i & 1) * STAGE;
+            PP_READ(st);
+            if (i >= 1 && i + 1 < nt) PP_ISSUE(i + 1, (i + 1) & 1, 6);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();  // end of A_i
+            __builtin_amdgcn_s_setprio(1);
+            PP_MFMA(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();  // end of B1_i
+            PP_MFMA(1);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // end of B2_i
+        }
+    } else {
+        for (int i = 0; i < nt; ++i) {
+            if (i >= 1) {
+                __builtin_amdgcn_s_setprio(1);
+                PP_MFMA(2);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_barrier();  // end of A_i
+            const char* st = smem + (i & 1) * STAGE;
+            PP_READ(st);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();  // end of B1_i
+            if (i + 2 < nt) {
+                PP_ISSUE(i + 2, i & 1, 8);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();  // end of B2_i
+        }
+        PP_MFMA(2);
+    }
+#undef PP_ISSUE
+#undef PP_READ
+#undef PP_MFMA
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + lr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int n = n0 + wn * 96 + 32 * k + 8 * lg;
+            if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi]);
+            else if (n < p.N) epilogue4(p, m, n, acc[2 * k][mi][0], acc[2 * k][mi][1], acc[2 * k][mi][2], acc[2 * k][mi][3]);
+        }
+    }
+}
+
 static int fill_operands(GemmParams& p, int precision, const u16* A_hi, const u16* A_lo, const u16* W_hi, const u16* W_lo) {
     p.A_hi = A_hi; p.W_hi = W_hi;
     if (precision == DIDI_PREC_BF16 || precision == DIDI_PREC_FP16) {
@@ -529,8 +752,19 @@ static bool opt_in_lds() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<NPASS, MT, F16>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<MT>::STAGE) == hipSuccess;
 }
+template <int NPASS, bool F16>
+static bool opt_in_lds_pp() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<NPASS, F16>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE) == hipSuccess;
+}
+// experiment knob: DIDI_GEMM_PP=0 selects the in-phase K-loop (gemm_big_kernel) for A/B timing
+static bool gemm_pp_enabled() {
+    static const bool v = [] { const char* e = getenv("DIDI_GEMM_PP"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
 static bool allow_big_lds() {  // > 64 KiB of dynamic LDS needs an opt-in, once per process
-    static const bool ok = opt_in_lds<3, 4, false>() && opt_in_lds<1, 4, false>() && opt_in_lds<1, 4, true>() &&
+    static const bool ok = opt_in_lds_pp<3, false>() && opt_in_lds_pp<1, false>() && opt_in_lds_pp<1, true>() &&
+                           opt_in_lds<3, 4, false>() && opt_in_lds<1, 4, false>() && opt_in_lds<1, 4, true>() &&
                            opt_in_lds<3, 2, false>() && opt_in_lds<1, 2, false>() && opt_in_lds<1, 2, true>();
     return ok;
 }
@@ -572,6 +806,18 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
         if (!allow_big_lds()) return DIDI_ERR_LAUNCH;
         p.tiles_n = big_tiles_n;
         const bool mt4 = gemm_big_mt() == 4;
+        const bool wide_ok = a->ldc % 8 == 0 && al16(a->C_hi) && al16(a->C_lo) && al16(a->R_hi) && al16(a->R_lo) &&
+                             (!(a->R_f32 || a->R_hi) || a->ldr % 8 == 0);
+        if (mt4 && wide_ok && gemm_pp_enabled()) {
+            p.tiles_m = cdiv(p.M, 256);
+            const int grid = p.tiles_m * p.tiles_n;
+            const size_t lds = 2 * BigGeom<4>::STAGE;
+            if (mode == 3) gemm_pp_kernel<3, false><<<grid, 512, lds, st>>>(p);
+            else if (p.f16) gemm_pp_kernel<1, true><<<grid, 512, lds, st>>>(p);
+            else gemm_pp_kernel<1, false><<<grid, 512, lds, st>>>(p);
+            DIDI_LAUNCH_CHECK();
+            return DIDI_OK;
+        }
         if (mode == 3) { if (mt4) launch_big<3, 4, false>(p, st); else launch_big<3, 2, false>(p, st); }
         else if (p.f16) { if (mt4) launch_big<1, 4, true>(p, st); else launch_big<1, 2, true>(p, st); }
         else { if (mt4) launch_big<1, 4, false>(p, st); else launch_big<1, 2, false>(p, st); }

@@ -35,13 +35,15 @@ def main():
         ("ffn_up   gelu", I, H, dict(act="gelu")),
         ("ffn_down f32+res", H, I, dict(resid=True)),
     ]
-    total = {"bf16": 0.0, "bf16x3": 0.0}
+    total = {"fp16": 0.0, "bf16x3": 0.0}
     for name, N, K, kw in shapes:
-        a_hi, a_lo = ops.split(rnd(M, K))
-        w_hi, w_lo = ops.split(rnd(N, K) * 0.02)
+        a32, w32, r32 = rnd(M, K), rnd(N, K) * 0.02, rnd(M, N)
         bias = rnd(N)
-        r = ops.split(rnd(M, N)) if kw.get("resid") else None
-        for prec in ("bf16", "bf16x3"):
+        for prec in ("fp16", "bf16x3"):
+            pd = ops.plane_dtype(prec)
+            a_hi, a_lo = ops.split(a32, dtype=pd)
+            w_hi, w_lo = ops.split(w32, dtype=pd)
+            r = ops.split(r32, dtype=pd) if kw.get("resid") else None
             call = lambda: ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias, act=kw.get("act"), precision=prec,  # noqa: E731
                                     residual_planes=r, out_f32=bool(r), out_planes=not r, out_lo=prec == "bf16x3")
             for _ in range(3):

@@ -52,6 +52,13 @@ __device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo, i
     hi = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
     lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
+// hi plane only (callers that do not keep the remainder)
+__device__ __forceinline__ uint2 pack4_hi(const float v[4], int f16 = 0) {
+    u16 h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = f16 ? f16_bits(v[i]) : bf16_bits(v[i]);
+    return make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+}
 __device__ __forceinline__ void unpack4(uint2 p, float v[4], int f16 = 0) {
     const u16 b[4] = {(u16)(p.x & 0xffff), (u16)(p.x >> 16), (u16)(p.y & 0xffff), (u16)(p.y >> 16)};
 #pragma unroll

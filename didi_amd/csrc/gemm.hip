@@ -362,12 +362,15 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32
         *reinterpret_cast<float4*>(p.C_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(p.C_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
     }
-    if (p.C_hi) {
+    if (p.C_hi && p.C_lo) {
         uint2 h0, l0, h1, l1;
         split4(v, h0, l0, p.f16);
         split4(v + 4, h1, l1, p.f16);
         *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        if (p.C_lo) *reinterpret_cast<uint4*>(p.C_lo + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        *reinterpret_cast<uint4*>(p.C_lo + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    } else if (p.C_hi) {  // one-product precisions keep no remainder of GEMM-only operands
+        const uint2 h0 = pack4_hi(v, p.f16), h1 = pack4_hi(v + 4, p.f16);
+        *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
     }
 }
 
@@ -652,9 +655,16 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         }                                                                                                  \
     } while (0)
 
-    if (grp == 0) { PP_ISSUE(0, 0, 6); if (nt > 1) PP_ISSUE(1, 1, 6); }
-    else { PP_ISSUE(0, 0, 8); if (nt > 1) PP_ISSUE(1, 1, 8); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile 0 must have landed before the first read; tile 1 stays in flight (first waits: end of B2_0)
+    if (grp == 0) {
+        PP_ISSUE(0, 0, 6);
+        if (nt > 1) { PP_ISSUE(1, 1, 6); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        PP_ISSUE(0, 0, 8);
+        if (nt > 1) { PP_ISSUE(1, 1, 8); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if (grp == 0) {
         for (int i = 0; i < nt; ++i) {

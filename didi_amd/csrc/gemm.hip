@@ -289,6 +289,22 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 
+// GELU for the one-product precisions (gemm_pp_kernel): GELU(x) = max(x, 0) - g(|x|) with
+// g(a) = a (1 - Phi(a)) read from a 1024-interval table in LDS and interpolated linearly (3.4e-6
+// absolute, the result is rounded to an 11- or 8-bit mantissa right after).  8 VALU + one ds_read_b64
+// instead of 14 VALU + v_rcp + v_exp: the erf form cost the FFN-up launch 45 us of pure VALU time
+// with the MFMA pipe idle (tools/epi_probe.py).  bf16x3 keeps the 1.5e-7 erf form.
+__device__ const float2 didi_gelu_table[1024] = {
+#include "gelu_table.inc"
+};
+__device__ __forceinline__ float gelu_lut(float x, const float2* tbl) {
+    const float u = fminf(fabsf(x) * (1024.0f / 6.0f), 1023.0f);
+    const int i = (int)u;
+    const float f = u - (float)i;
+    const float2 c = tbl[i];
+    return fmaxf(x, 0.0f) - (c.x + f * c.y);
+}
+
 // epilogue for 4 consecutive output columns n..n+3 of row m: bias, activation, residual, stores
 __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, float v0, float v1, float v2, float v3) {
     if (p.bias) {
@@ -325,7 +341,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
 
 // the same for 8 consecutive output columns: 16-byte plane stores / loads instead of 8-byte ones (the
 // epilogue is store-issue bound: half the instructions, twice the contiguous bytes per row)
-__device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32x4 lo4, f32x4 hi4) {
+__device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32x4 lo4, f32x4 hi4, const float2* gelu_tbl) {
     float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     if (p.bias) {
         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
@@ -333,7 +349,10 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32
         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
         v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
     }
-    if (p.act != DIDI_ACT_NONE) {
+    if (p.act == DIDI_ACT_GELU && gelu_tbl) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gelu_lut(v[i], gelu_tbl);
+    } else if (p.act != DIDI_ACT_NONE) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = act_apply(v[i], p.act);
     }
@@ -655,6 +674,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         }                                                                                                  \
     } while (0)
 
+    // one-product GELU launches: the 8-KiB table rides behind the stages, one LDS-DMA piece per wave,
+    // issued first so that every later counted wait covers it
+    const bool use_lut = NPASS == 1 && p.act == DIDI_ACT_GELU;
+    if (use_lut) glds16(reinterpret_cast<const u16*>(didi_gelu_table) + wave * 512 + lane * 8, smem + 2 * STAGE + wave * 1024);
     // tile 0 must have landed before the first read; tile 1 stays in flight (first waits: end of B2_0)
     if (grp == 0) {
         PP_ISSUE(0, 0, 6);
@@ -711,6 +734,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #undef PP_ISSUE
 #undef PP_READ
 #undef PP_MFMA
+    const float2* gelu_tbl = use_lut ? reinterpret_cast<const float2*>(smem + 2 * STAGE) : nullptr;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wm * 64 + mi * 16 + lr;
@@ -718,7 +742,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int n = n0 + wn * 96 + 32 * k + 8 * lg;
-            if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi]);
+            if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi], gelu_tbl);
             else if (n < p.N) epilogue4(p, m, n, acc[2 * k][mi][0], acc[2 * k][mi][1], acc[2 * k][mi][2], acc[2 * k][mi][3]);
         }
     }
@@ -765,7 +789,7 @@ static bool opt_in_lds() {
 template <int NPASS, bool F16>
 static bool opt_in_lds_pp() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<NPASS, F16>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE) == hipSuccess;
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess;
 }
 // experiment knob: DIDI_GEMM_PP=0 selects the in-phase K-loop (gemm_big_kernel) for A/B timing
 static bool gemm_pp_enabled() {
@@ -821,7 +845,7 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
         if (mt4 && wide_ok && gemm_pp_enabled()) {
             p.tiles_m = cdiv(p.M, 256);
             const int grid = p.tiles_m * p.tiles_n;
-            const size_t lds = 2 * BigGeom<4>::STAGE;
+            const size_t lds = 2 * BigGeom<4>::STAGE + 8192;  // + GELU table
             if (mode == 3) gemm_pp_kernel<3, false><<<grid, 512, lds, st>>>(p);
             else if (p.f16) gemm_pp_kernel<1, true><<<grid, 512, lds, st>>>(p);
             else gemm_pp_kernel<1, false><<<grid, 512, lds, st>>>(p);

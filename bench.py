@@ -170,7 +170,7 @@ def main():
             traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
             traffic_src = os.path.relpath(tpath, ROOT)
         roofline = {
-            "bound": "mfma", "kernel": f"gemm_big_kernel<{3 if args.precision == 'bf16x3' else 1},4,{'true' if args.precision == 'fp16' else 'false'}> (256x192 tile)",
+            "bound": "mfma", "kernel": f"gemm_pp_kernel<{3 if args.precision == 'bf16x3' else 1},{'true' if args.precision == 'fp16' else 'false'}> (256x192 tile, staggered wave groups)",
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches": len(dur), "avg_launch_us": round(1e3 * sum(dur) / len(dur), 2),

@@ -17,15 +17,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--M", type=int, default=16384)
 ap.add_argument("--N", type=int, default=768)
 ap.add_argument("--K", type=int, default=3072)
-ap.add_argument("--precision", default="bf16x3")
+ap.add_argument("--precision", default="fp16")
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--epi", default="planes")
 a = ap.parse_args()
 g = torch.Generator(device="cuda").manual_seed(0)
-x_hi, x_lo = ops.split(torch.randn(a.M, a.K, device="cuda", generator=g))
-w_hi, w_lo = ops.split(torch.randn(a.N, a.K, device="cuda", generator=g) * 0.02)
+pd = ops.plane_dtype(a.precision)
+x_hi, x_lo = ops.split(torch.randn(a.M, a.K, device="cuda", generator=g), dtype=pd)
+w_hi, w_lo = ops.split(torch.randn(a.N, a.K, device="cuda", generator=g) * 0.02, dtype=pd)
 bias = torch.randn(a.N, device="cuda", generator=g)
-r = ops.split(torch.randn(a.M, a.N, device="cuda", generator=g)) if a.epi == "f32res" else None
+r = ops.split(torch.randn(a.M, a.N, device="cuda", generator=g), dtype=pd) if a.epi == "f32res" else None
 for _ in range(a.iters):
     ops.gemm(x_hi, x_lo, w_hi, w_lo, bias=bias, act="gelu" if a.epi == "gelu" else None, precision=a.precision,
              residual_planes=r, out_f32=bool(r), out_planes=not r, out_lo=a.precision == "bf16x3")

@@ -20,7 +20,7 @@ def per_launch(path, counter, kernel):
 
 def main():
     fetch_csv, write_csv, out = sys.argv[1:4]
-    kernel = sys.argv[4] if len(sys.argv) > 4 else "gemm_big_kernel"
+    kernel = sys.argv[4] if len(sys.argv) > 4 else "gemm_pp_kernel"
     fetch, n = per_launch(fetch_csv, "FETCH_SIZE", kernel)
     write, _ = per_launch(write_csv, "WRITE_SIZE", kernel)
     res = {"kernel": kernel, "launches": n, "fetch_bytes_per_launch_corrected_x2": 2 * fetch, "write_bytes_per_launch": write,

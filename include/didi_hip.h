@@ -125,13 +125,15 @@ int didi_layernorm(const float* x, const float* gamma, const float* beta, float 
 /* ---------------------------------------------------------------- GEMM (MFMA bf16) */
 
 /* C[M,N] = epilogue( sum_p A_p[M,K] * W_p[N,K]^T ), fp32 accumulation on
- * v_mfma_f32_16x16x32_bf16.  W is an nn.Linear weight as stored ([out, in] = [N, K], K
+ * v_mfma_f32_16x16x32_bf16 / _f16 (the name keeps "bf16" from ABI v1; all three precisions go here).  W is an nn.Linear weight as stored ([out, in] = [N, K], K
  * contiguous), pre-split into planes.  Replaces every nn.Linear on the path:
  * Bert query/key/value/dense (HF:models/bert/modeling_bert.py:175-177,244,253-254,290,335,348),
  * the adapter (src/diffusion/model.py:123), `classifier` (src/sampling.py:64,82).
  *   precision : DIDI_PREC_BF16 / DIDI_PREC_FP16 (A_hi*W_hi) or DIDI_PREC_BF16X3 (+ A_hi*W_lo + A_lo*W_hi)
  *   epilogue  : v = acc (+ bias[n]) ; v = act(v) ; v += residual[m,n]
- *               act: 0 none, 1 exact-erf GELU (hidden_act="gelu"), 2 tanh
+ *               act: 0 none, 1 exact-erf GELU (hidden_act="gelu"; evaluated to <= 1.5e-7 in BF16X3 and to
+ *               <= 3.4e-6 absolute -- a table -- in the one-product precisions, whose outputs are rounded
+ *               to 16 bits right after), 2 tanh
  *               residual: fp32 [M, ldr] or split planes (hi+lo), or none
  *   outputs   : any of fp32 C_f32 [M, ldc] and split planes C_hi/C_lo [M, ldc]
  * Constraints: K % 8 == 0, N % 4 == 0, lda/ldw % 8 == 0, ldc % 4 == 0, pointers 16-byte aligned. */

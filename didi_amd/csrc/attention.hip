@@ -23,6 +23,8 @@
 // context) keys take the most negative finite float; LDS padding keys are excluded outright.
 //
 // ds_read_b64_tr_b16 needs EXEC all ones: every branch around it below is wave-uniform.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 struct AttnParams {
@@ -36,6 +38,7 @@ struct AttnParams {
     u16* O[2]; int ldo;
     int SP, CP;  // padded lengths: SP % 16 == 0, CP % 32 == 0
     int d;       // true head dim (multiple of 8, <= D); columns d..D-1 are zero padding in LDS
+    int nh;      // heads per workgroup (divides heads)
 };
 
 typedef short v4s __attribute__((ext_vector_type(4)));
@@ -64,190 +67,218 @@ __device__ __forceinline__ bf16x8 ld_q(const u16* q, bool ok) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int D, int NPASS, bool F16>
+// NJ = 16-byte chunks of one K (or V) plane image each thread stages: ceil(CP * D/8 / 256), 2 or 3
+template <int D, int NPASS, bool F16, int NJ, bool MULTI>
 __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
     constexpr int NPL = NPASS == 3 ? 2 : 1;
     constexpr int CH = D / 8;   // 16-byte chunks per row
     constexpr int KS = D / 32;  // MFMA k-steps over the head dim
     constexpr float NEG = -3.4028234663852886e38f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int head = blockIdx.x, b = blockIdx.y;
+    const int b = blockIdx.y, head0 = blockIdx.x * p.nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const int CP = p.CP;
     const int plane = CP * D * 2;  // bytes per K / V plane image
     char* Ks = smem;
     char* Vs = Ks + NPL * plane;
-    int* mk = reinterpret_cast<int*>(Vs + NPL * plane);  // [CP] 0 visible, 1 masked, 2 padding
+    float* mb = reinterpret_cast<float*>(Vs + NPL * plane);  // [CP] additive key bias: 0, NEG (masked) or -inf (padding)
 
     const int nqb = p.SP / 16;
     const int nkt_real = (p.Sk + 15) / 16;
-    const u16* qh_base = p.Q[0] + (size_t)b * p.Sq * p.ldq + head * p.d;
-    const u16* ql_base = NPL == 2 ? p.Q[1] + (size_t)b * p.Sq * p.ldq + head * p.d : nullptr;
 
-    // ---- Q fragments of this wave's first block: global -> registers, in flight during the staging
-    bf16x8 qh0, qh1, ql0, ql1;
-    qh0 = qh1 = ql0 = ql1 = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
-#define DIDI_LOAD_Q(qb_)                                                              \
-    do {                                                                              \
-        const int q_ = (qb_) * 16 + lr;                                               \
-        const size_t ro_ = (size_t)q_ * p.ldq;                                        \
-        const bool ok0_ = q_ < p.Sq && lg * 8 < p.d;                                  \
-        const bool ok1_ = q_ < p.Sq && 32 + lg * 8 < p.d;                             \
-        qh0 = ld_q(qh_base + ro_ + lg * 8, ok0_);                                     \
-        if constexpr (KS == 2) qh1 = ld_q(qh_base + ro_ + 32 + lg * 8, ok1_);         \
-        if constexpr (NPL == 2) {                                                     \
-            ql0 = ld_q(ql_base + ro_ + lg * 8, ok0_);                                 \
-            if constexpr (KS == 2) ql1 = ld_q(ql_base + ro_ + 32 + lg * 8, ok1_);     \
-        }                                                                             \
+    // Q fragments of one 16-query block: global -> registers (B-operand rows)
+    bf16x8 qh0, qh1, ql0, ql1, nh0, nh1, nl0, nl1;
+    qh0 = qh1 = ql0 = ql1 = nh0 = nh1 = nl0 = nl1 = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+#define DIDI_LOAD_Q(H0, H1, L0, L1, head_, qb_)                                                        \
+    do {                                                                                               \
+        const int q_ = (qb_) * 16 + lr;                                                                \
+        const size_t ro_ = ((size_t)b * p.Sq + q_) * p.ldq + (head_) * p.d;                            \
+        const bool ok0_ = q_ < p.Sq && lg * 8 < p.d;                                                   \
+        const bool ok1_ = q_ < p.Sq && 32 + lg * 8 < p.d;                                              \
+        H0 = ld_q(p.Q[0] + ro_ + lg * 8, ok0_);                                                        \
+        if constexpr (KS == 2) H1 = ld_q(p.Q[0] + ro_ + 32 + lg * 8, ok1_);                            \
+        if constexpr (NPL == 2) {                                                                      \
+            L0 = ld_q(p.Q[1] + ro_ + lg * 8, ok0_);                                                    \
+            if constexpr (KS == 2) L1 = ld_q(p.Q[1] + ro_ + 32 + lg * 8, ok1_);                        \
+        }                                                                                              \
     } while (0)
-    if (wave < nqb) DIDI_LOAD_Q(wave);
 
-    // ---- stage K, V (all global loads first, then the LDS writes) and the key flags
-    {
-        uint4 kr[3][NPL], vr[3][NPL];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int i = tid + j * 256;
-            const int r = i / CH, c = i % CH;
-            const bool ok = r < p.Sk && c * 8 < p.d;
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
-                kr[j][pl] = make_uint4(0, 0, 0, 0);
-                vr[j][pl] = make_uint4(0, 0, 0, 0);
-                if (ok) {
-                    kr[j][pl] = *reinterpret_cast<const uint4*>(p.K[pl] + ((size_t)b * p.Sk + r) * p.ldk + head * p.d + c * 8);
-                    vr[j][pl] = *reinterpret_cast<const uint4*>(p.V[pl] + ((size_t)b * p.Sk + r) * p.ldv + head * p.d + c * 8);
-                }
-            }
-        }
-        for (int c = tid; c < CP; c += 256) {
-            int f = 0;
-            if (c >= p.Sk) f = 2;
-            else if (p.key_mask && p.key_mask[(size_t)b * p.Sk + c] == 0) f = 1;
-            mk[c] = f;
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int i = tid + j * 256;
-            const int r = i / CH, c = i % CH;
-            if (r < CP) {
-                const int o = img_off<D>(r, c);
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) {
-                    *reinterpret_cast<uint4*>(Ks + pl * plane + o) = kr[j][pl];
-                    *reinterpret_cast<uint4*>(Vs + pl * plane + o) = vr[j][pl];
-                }
-            }
-        }
+    // K, V of one head: global -> registers (zero past Sk / past the true head dim), registers -> LDS
+    uint4 kr[NJ][NPL], vr[NJ][NPL];
+#define DIDI_LOAD_KV(head_)                                                                            \
+    do {                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                               \
+            const int i_ = tid + j * 256;                                                              \
+            const int r_ = i_ / CH, c_ = i_ % CH;                                                      \
+            const bool ok_ = r_ < p.Sk && c_ * 8 < p.d;                                                \
+            _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                       \
+                kr[j][pl] = make_uint4(0, 0, 0, 0);                                                    \
+                vr[j][pl] = make_uint4(0, 0, 0, 0);                                                    \
+                if (ok_) {                                                                             \
+                    kr[j][pl] = *reinterpret_cast<const uint4*>(p.K[pl] + ((size_t)b * p.Sk + r_) * p.ldk + (head_) * p.d + c_ * 8); \
+                    vr[j][pl] = *reinterpret_cast<const uint4*>(p.V[pl] + ((size_t)b * p.Sk + r_) * p.ldv + (head_) * p.d + c_ * 8); \
+                }                                                                                      \
+            }                                                                                          \
+        }                                                                                              \
+    } while (0)
+#define DIDI_STORE_KV()                                                                                \
+    do {                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                               \
+            const int i_ = tid + j * 256;                                                              \
+            const int r_ = i_ / CH, c_ = i_ % CH;                                                      \
+            if (r_ < CP) {                                                                             \
+                const int o_ = img_off<D>(r_, c_);                                                     \
+                _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                   \
+                    *reinterpret_cast<uint4*>(Ks + pl * plane + o_) = kr[j][pl];                       \
+                    *reinterpret_cast<uint4*>(Vs + pl * plane + o_) = vr[j][pl];                       \
+                }                                                                                      \
+            }                                                                                          \
+        }                                                                                              \
+    } while (0)
+
+    if (wave < nqb) DIDI_LOAD_Q(qh0, qh1, ql0, ql1, head0, wave);
+    DIDI_LOAD_KV(head0);
+    for (int c = tid; c < CP; c += 256) {
+        float f = 0.f;
+        if (c >= p.Sk) f = -INFINITY;
+        else if (p.key_mask && p.key_mask[(size_t)b * p.Sk + c] == 0) f = NEG;
+        mb[c] = f;
     }
+    DIDI_STORE_KV();
     __syncthreads();
 
-    u16* oh = p.O[0] + (size_t)b * p.Sq * p.ldo + head * p.d;
-    u16* ol = NPL == 2 ? p.O[1] + (size_t)b * p.Sq * p.ldo + head * p.d : nullptr;
+    // a workgroup walks p.nh heads of its dialog: the next head's K, V and Q are in flight (registers)
+    // while the current head is computed from LDS
+    for (int hh = 0; hh < (MULTI ? p.nh : 1); ++hh) {
+        const int head = head0 + hh;
+        const bool more = MULTI && hh + 1 < p.nh;
+        if (more) {
+            DIDI_LOAD_KV(head + 1);
+            if (wave < nqb) DIDI_LOAD_Q(nh0, nh1, nl0, nl1, head + 1, wave);
+        }
+        u16* oh = p.O[0] + (size_t)b * p.Sq * p.ldo + head * p.d;
+        u16* ol = NPL == 2 ? p.O[1] + (size_t)b * p.Sq * p.ldo + head * p.d : nullptr;
 
-    for (int qb = wave; qb < nqb; qb += 4) {
-        if (qb != wave) DIDI_LOAD_Q(qb);
-        const int nkt = p.causal ? min(qb + 1, nkt_real) : nkt_real;
-        const int nks = (nkt + 1) / 2;
-        const int q = qb * 16 + lr;
-        float sc[6][4];
-        float rmax = NEG, rsum = 0.f;
-        // ---- scores: lane holds S[q][16*kt + 4*lg + r]
+        for (int qb = wave; qb < nqb; qb += 4) {
+            if (qb != wave) DIDI_LOAD_Q(qh0, qh1, ql0, ql1, head, qb);
+            const int nkt = p.causal ? min(qb + 1, nkt_real) : nkt_real;
+            const int nks = (nkt + 1) / 2;
+            const int q = qb * 16 + lr;
+            float sc[6][4];
+            float rmax = NEG, rsum = 0.f;
+            // ---- scores: lane holds S[q][16*kt + 4*lg + r]
 #pragma unroll
-        for (int kt = 0; kt < 6; ++kt) {
-            if (kt < nkt) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < 6; ++kt) {
+                if (kt < nkt) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const int ko = img_off<D>(kt * 16 + lr, ks * 4 + lg);
-                    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Ks + ko);
-                    const bf16x8 qh = ks ? qh1 : qh0;
-                    if constexpr (NPASS == 3) {
-                        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Ks + plane + ko);
-                        const bf16x8 ql = ks ? ql1 : ql0;
-                        acc = mma16<F16>(kl, qh, acc);
-                        acc = mma16<F16>(kh, ql, acc);
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const int ko = img_off<D>(kt * 16 + lr, ks * 4 + lg);
+                        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Ks + ko);
+                        const bf16x8 qh = ks ? qh1 : qh0;
+                        if constexpr (NPASS == 3) {
+                            const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Ks + plane + ko);
+                            const bf16x8 ql = ks ? ql1 : ql0;
+                            acc = mma16<F16>(kl, qh, acc);
+                            acc = mma16<F16>(kh, ql, acc);
+                        }
+                        acc = mma16<F16>(kh, qh, acc);
                     }
-                    acc = mma16<F16>(kh, qh, acc);
+                    // masked keys: score + NEG rounds to NEG exactly, the reference's additive mask
+                    const float4 m4 = *reinterpret_cast<const float4*>(mb + kt * 16 + lg * 4);
+                    sc[kt][0] = fmaf(acc[0], p.scale, m4.x);
+                    sc[kt][1] = fmaf(acc[1], p.scale, m4.y);
+                    sc[kt][2] = fmaf(acc[2], p.scale, m4.z);
+                    sc[kt][3] = fmaf(acc[3], p.scale, m4.w);
+                    if (p.causal && kt == qb) {  // only the diagonal tile holds future keys
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kt * 16 + lg * 4 + r > q) sc[kt][r] = fminf(sc[kt][r], NEG);
+                    }
+                    rmax = fmaxf(rmax, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[kt][r] = -INFINITY;
                 }
-                const int4 f4 = *reinterpret_cast<const int4*>(mk + kt * 16 + lg * 4);
-                const int fl[4] = {f4.x, f4.y, f4.z, f4.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 16 + lg * 4 + r;
-                    float s = acc[r] * p.scale;
-                    if (fl[r] == 1 || (p.causal && key > q)) s = NEG;
-                    if (fl[r] == 2) s = -INFINITY;
-                    sc[kt][r] = s;
-                    rmax = fmaxf(rmax, s);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sc[kt][r] = -INFINITY;
             }
-        }
-        rmax = fmaxf(rmax, __shfl_xor(rmax, 16, 64));
-        rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
-        // ---- probabilities (unnormalised; the row sum divides O at the end) -> B-operand fragments:
-        //      k-step s, element e: key 32*s + 16*(e>>2) + 4*lg + (e&3)
-        v8s ph[3], pl[3];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int kt = 2 * s + (e >> 2);
-                // scores carry log2(e): one v_exp_f32 per probability (libm expf cost ~3x the MFMA work of a block)
-                const float pr = (kt < nkt) ? __builtin_amdgcn_exp2f(sc[kt][e & 3] - rmax) : 0.f;
-                rsum += pr;
-                u16 h, l;
-                split2(pr, h, l, F16);
-                ph[s][e] = (short)h;
-                pl[s][e] = (short)l;
-            }
-        }
-        rsum += __shfl_xor(rsum, 16, 64);
-        rsum += __shfl_xor(rsum, 32, 64);
-        const float rinv = 1.0f / rsum;
-        // ---- O^T = V^T P^T; A-operand element e of lane (lr, lg) = V[key(s, lg, e)][16*dt + lr]
-        const int trow = 4 * lg + (lr >> 2);  // row of the 4x16 block this lane addresses
-        const int tsub = 8 * (lr & 1);
-#pragma unroll
-        for (int dt = 0; dt < D / 16; ++dt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const int cch = 2 * dt + ((lr & 3) >> 1);
+            rmax = fmaxf(rmax, __shfl_xor(rmax, 16, 64));
+            rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+            // ---- probabilities (unnormalised; the row sum divides O at the end) -> B-operand fragments:
+            //      k-step s, element e: key 32*s + 16*(e>>2) + 4*lg + (e&3).  Scores carry log2(e): one
+            //      v_exp_f32 per probability; exp2(-inf) = 0 covers padding keys and absent tiles.
+            v8s ph[3], pl[3];
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
+                ph[s] = v8s{0, 0, 0, 0, 0, 0, 0, 0};
+                pl[s] = v8s{0, 0, 0, 0, 0, 0, 0, 0};
                 if (s < nks) {
-                    const int o0 = img_off<D>(32 * s + trow, cch) + tsub;
-                    const int o1 = img_off<D>(32 * s + 16 + trow, cch) + tsub;
-                    const bf16x8 vh = cat8(lds_tr_read(Vs + o0), lds_tr_read(Vs + o1));
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, ph[s]);
-                    if constexpr (NPASS == 3) {
-                        const bf16x8 vl = cat8(lds_tr_read(Vs + plane + o0), lds_tr_read(Vs + plane + o1));
-                        const bf16x8 bl = __builtin_bit_cast(bf16x8, pl[s]);
-                        acc = mma16<F16>(vl, bh, acc);
-                        acc = mma16<F16>(vh, bl, acc);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float pr = __builtin_amdgcn_exp2f(sc[2 * s + (e >> 2)][e & 3] - rmax);
+                        rsum += pr;
+                        u16 h, l;
+                        split2(pr, h, l, F16);
+                        ph[s][e] = (short)h;
+                        pl[s][e] = (short)l;
                     }
-                    acc = mma16<F16>(vh, bh, acc);
                 }
             }
-            const int d0 = dt * 16 + lg * 4;
-            if (q < p.Sq && d0 < p.d) {
-                const float o[4] = {acc[0] * rinv, acc[1] * rinv, acc[2] * rinv, acc[3] * rinv};
-                uint2 h2, l2;
-                split4(o, h2, l2, F16);
-                const size_t off = (size_t)q * p.ldo + d0;
-                *reinterpret_cast<uint2*>(oh + off) = h2;
-                if (ol) *reinterpret_cast<uint2*>(ol + off) = l2;
+            rsum += __shfl_xor(rsum, 16, 64);
+            rsum += __shfl_xor(rsum, 32, 64);
+            const float rinv = 1.0f / rsum;
+            // ---- O^T = V^T P^T; A-operand element e of lane (lr, lg) = V[key(s, lg, e)][16*dt + lr]
+            const int trow = 4 * lg + (lr >> 2);  // row of the 4x16 block this lane addresses
+            const int tsub = 8 * (lr & 1);
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const int cch = 2 * dt + ((lr & 3) >> 1);
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    if (s < nks) {
+                        const int o0 = img_off<D>(32 * s + trow, cch) + tsub;
+                        const int o1 = img_off<D>(32 * s + 16 + trow, cch) + tsub;
+                        const bf16x8 vh = cat8(lds_tr_read(Vs + o0), lds_tr_read(Vs + o1));
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, ph[s]);
+                        if constexpr (NPASS == 3) {
+                            const bf16x8 vl = cat8(lds_tr_read(Vs + plane + o0), lds_tr_read(Vs + plane + o1));
+                            const bf16x8 bl = __builtin_bit_cast(bf16x8, pl[s]);
+                            acc = mma16<F16>(vl, bh, acc);
+                            acc = mma16<F16>(vh, bl, acc);
+                        }
+                        acc = mma16<F16>(vh, bh, acc);
+                    }
+                }
+                const int d0 = dt * 16 + lg * 4;
+                if (q < p.Sq && d0 < p.d) {
+                    const float o[4] = {acc[0] * rinv, acc[1] * rinv, acc[2] * rinv, acc[3] * rinv};
+                    const size_t off = (size_t)q * p.ldo + d0;
+                    if (ol) {
+                        uint2 h2, l2;
+                        split4(o, h2, l2, F16);
+                        *reinterpret_cast<uint2*>(oh + off) = h2;
+                        *reinterpret_cast<uint2*>(ol + off) = l2;
+                    } else {
+                        *reinterpret_cast<uint2*>(oh + off) = pack4_hi(o, F16);
+                    }
+                }
             }
+        }
+        if (more) {
+            __syncthreads();  // every wave is done with this head's K / V image
+            DIDI_STORE_KV();
+            qh0 = nh0; qh1 = nh1; ql0 = nl0; ql1 = nl1;
+            __syncthreads();
         }
     }
 #undef DIDI_LOAD_Q
+#undef DIDI_LOAD_KV
+#undef DIDI_STORE_KV
 }
 
 static size_t attn_lds_bytes(int D, int npl, int CP) {
-    return (size_t)2 * npl * CP * D * 2 + CP * sizeof(int);
+    return (size_t)2 * npl * CP * D * 2 + CP * sizeof(float);
 }
 
 extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
@@ -276,17 +307,34 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
     p.SP = (a->Sq + 15) / 16 * 16;
     p.CP = (a->Sk + 31) / 32 * 32;
     const size_t lds = attn_lds_bytes(DP, x3 ? 2 : 1, p.CP);  // <= 48.4 KiB: 3-4 workgroups per CU
-    dim3 grid(a->heads, a->B);
+    // experiment knob DIDI_ATTN_NH=2|3: heads per workgroup.  Measured at B=256, 12 heads, S=64 (tools/attn_bench.py):
+    // one head 19.2 / 20.9 us (fp16 self / cross), two heads 23.8 / 24.3, three 24.2 / 24.0 -- the kernel is bound by
+    // its per-wave dependency chains, so 8 waves per SIMD beat prefetching with 4; the default stays 1.
+    static const int nh_env = [] { const char* e = getenv("DIDI_ATTN_NH"); return e ? atoi(e) : 1; }();
+    p.nh = (nh_env == 3 && a->heads % 3 == 0) ? 3 : (nh_env >= 2 && a->heads % 2 == 0 ? 2 : 1);
+    dim3 grid(a->heads / p.nh, a->B);
     hipStream_t st = as_stream(stream);
+    const bool nj3 = p.CP * (DP / 8) > 512;
+#define DIDI_ATTN(DD, NP, FF)                                                        \
+    do {                                                                             \
+        if (p.nh > 1) {                                                              \
+            if (nj3) attn_kernel<DD, NP, FF, 3, true><<<grid, 256, lds, st>>>(p);    \
+            else attn_kernel<DD, NP, FF, 2, true><<<grid, 256, lds, st>>>(p);        \
+        } else {                                                                     \
+            if (nj3) attn_kernel<DD, NP, FF, 3, false><<<grid, 256, lds, st>>>(p);   \
+            else attn_kernel<DD, NP, FF, 2, false><<<grid, 256, lds, st>>>(p);       \
+        }                                                                            \
+    } while (0)
     if (DP == 64) {
-        if (x3) attn_kernel<64, 3, false><<<grid, 256, lds, st>>>(p);
-        else if (f16) attn_kernel<64, 1, true><<<grid, 256, lds, st>>>(p);
-        else attn_kernel<64, 1, false><<<grid, 256, lds, st>>>(p);
+        if (x3) DIDI_ATTN(64, 3, false);
+        else if (f16) DIDI_ATTN(64, 1, true);
+        else DIDI_ATTN(64, 1, false);
     } else {
-        if (x3) attn_kernel<32, 3, false><<<grid, 256, lds, st>>>(p);
-        else if (f16) attn_kernel<32, 1, true><<<grid, 256, lds, st>>>(p);
-        else attn_kernel<32, 1, false><<<grid, 256, lds, st>>>(p);
+        if (x3) DIDI_ATTN(32, 3, false);
+        else if (f16) DIDI_ATTN(32, 1, true);
+        else DIDI_ATTN(32, 1, false);
     }
+#undef DIDI_ATTN
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

@@ -341,7 +341,9 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
 
 // the same for 8 consecutive output columns: 16-byte plane stores / loads instead of 8-byte ones (the
 // epilogue is store-issue bound: half the instructions, twice the contiguous bytes per row)
-__device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32x4 lo4, f32x4 hi4, const float2* gelu_tbl) {
+// `pre` != 0: the residual planes of these 8 columns were loaded ahead by the caller (rh_pre, rl_pre)
+__device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32x4 lo4, f32x4 hi4, const float2* gelu_tbl,
+                                          int pre = 0, uint4 rh_pre = uint4{0, 0, 0, 0}, uint4 rl_pre = uint4{0, 0, 0, 0}) {
     float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     if (p.bias) {
         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
@@ -362,14 +364,14 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32
         v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
         v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
     } else if (p.R_hi) {
-        const uint4 rh = *reinterpret_cast<const uint4*>(p.R_hi + (size_t)m * p.ldr + n);
+        const uint4 rh = pre ? rh_pre : *reinterpret_cast<const uint4*>(p.R_hi + (size_t)m * p.ldr + n);
         float r[4];
         unpack4(make_uint2(rh.x, rh.y), r, p.f16);
         v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
         unpack4(make_uint2(rh.z, rh.w), r, p.f16);
         v[4] += r[0]; v[5] += r[1]; v[6] += r[2]; v[7] += r[3];
         if (p.R_lo) {
-            const uint4 rl = *reinterpret_cast<const uint4*>(p.R_lo + (size_t)m * p.ldr + n);
+            const uint4 rl = pre ? rl_pre : *reinterpret_cast<const uint4*>(p.R_lo + (size_t)m * p.ldr + n);
             unpack4(make_uint2(rl.x, rl.y), r, p.f16);
             v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
             unpack4(make_uint2(rl.z, rl.w), r, p.f16);
@@ -735,15 +737,36 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #undef PP_READ
 #undef PP_MFMA
     const float2* gelu_tbl = use_lut ? reinterpret_cast<const float2*>(smem + 2 * STAGE) : nullptr;
+    // residual planes: all 12 loads of half a wave tile are issued before the first use (the fragment
+    // registers are dead by now), instead of one exposed memory round trip per 8 columns
+    const int pre = p.R_hi != nullptr && p.R_f32 == nullptr;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + lr;
-        if (m >= p.M) continue;
+    for (int half = 0; half < 2; ++half) {
+        uint4 rh[2][3], rl[2][3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int n = n0 + wn * 96 + 32 * k + 8 * lg;
-            if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi], gelu_tbl);
-            else if (n < p.N) epilogue4(p, m, n, acc[2 * k][mi][0], acc[2 * k][mi][1], acc[2 * k][mi][2], acc[2 * k][mi][3]);
+        for (int mj = 0; mj < 2; ++mj)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                rh[mj][k] = uint4{0, 0, 0, 0};
+                rl[mj][k] = uint4{0, 0, 0, 0};
+                const int m = m0 + wm * 64 + (half * 2 + mj) * 16 + lr;
+                const int n = n0 + wn * 96 + 32 * k + 8 * lg;
+                if (pre && m < p.M && n + 8 <= p.N) {
+                    rh[mj][k] = *reinterpret_cast<const uint4*>(p.R_hi + (size_t)m * p.ldr + n);
+                    if (p.R_lo) rl[mj][k] = *reinterpret_cast<const uint4*>(p.R_lo + (size_t)m * p.ldr + n);
+                }
+            }
+#pragma unroll
+        for (int mj = 0; mj < 2; ++mj) {
+            const int mi = half * 2 + mj;
+            const int m = m0 + wm * 64 + mi * 16 + lr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int n = n0 + wn * 96 + 32 * k + 8 * lg;
+                if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi], gelu_tbl, pre, rh[mj][k], rl[mj][k]);
+                else if (n < p.N) epilogue4(p, m, n, acc[2 * k][mi][0], acc[2 * k][mi][1], acc[2 * k][mi][2], acc[2 * k][mi][3]);
+            }
         }
     }
 }

@@ -6,7 +6,7 @@ DECODER's matmul operands (Linear inputs/weights, Q/K/V, softmax probabilities, 
 bf16 or fp16 -- products and accumulation stay fp32, as on the MFMA -- and reports the per-call x_t
 rel-L2 and the token-id agreement.  Test infrastructure only (imports oracle/).
 
-    python tools/precision_probe.py
+    python tests/precision_probe.py
 """
 import os
 import sys

@@ -144,6 +144,26 @@ def test_sample_errors_and_decode():
     assert [r.tolist() for r in rows] == [[5, 17], [1, 2, 3, 4]]
 
 
+def test_lightning_checkpoint_loader(tmp_path):
+    """A Lightning-layout .ckpt loads into the same sampler as the in-memory state dict."""
+    from didi_amd.checkpoint import load_lightning_checkpoint
+    from didi_amd.sampling import sample
+
+    t, meta = load_case("tiny_ddpm_f3_len8")
+    w = weights_of(load_case("tiny_weights")[0])
+    cfg = spec_to_config(meta["spec"])
+    path = tmp_path / "step_1.ckpt"
+    torch.save({"state_dict": w, "hyper_parameters": {"diffusion_steps": cfg.diffusion_steps, "schedule": cfg.schedule,
+                                                      "step_freq": 3, "opt_kwargs": {"lr": 1e-4}}}, path)
+    loaded = load_lightning_checkpoint(path, device="cuda", precision="fp16", dec_heads=cfg.dec_heads, enc_heads=cfg.enc_heads)
+    assert loaded.cfg.step_freq == 3 and loaded.cfg.dec_layers == cfg.dec_layers and loaded.cfg.enc_kind == cfg.enc_kind
+    ctx = _ctx(t["in.input_ids"], t["in.attention_mask"])
+    noise = torch.stack(noise_list(t, int(meta["n_noise"])))
+    a, _ = sample(ctx, loaded, "ddpm", 3, max_len=8, noise=noise, return_ids=True)
+    b, _ = sample(ctx, _model(w, cfg, "fp16"), "ddpm", 3, max_len=8, noise=noise, return_ids=True)
+    assert torch.equal(a, b)
+
+
 def test_torch_noise_loop_equals_native_loop():
     """The per-call Python loop and the native didi_sample loop run the same kernels: with the same
     injected draws they must agree bit-for-bit."""

@@ -101,7 +101,7 @@ class SampleArgs(C.Structure):
         ("cls_hi", C.c_void_p), ("cls_lo", C.c_void_p), ("V", C.c_int), ("argmax_partial", C.c_void_p),
         ("ids64", C.c_void_p),
         ("prof_call", C.c_int), ("prof_events_host", C.POINTER(C.c_void_p)), ("prof_capacity", C.c_int),
-        ("prof_used_host", C.POINTER(C.c_int)),
+        ("prof_used_host", C.POINTER(C.c_int)), ("clamp_emb", C.c_void_p),
     ]
 
 

@@ -191,6 +191,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
     if (s->euler) DIDI_CHECK_ARG(s->c2_host && s->x_state);
     if (s->ids64) DIDI_CHECK_ARG(s->cls_hi && s->argmax_partial && s->x0_hi && s->V > 0);
     if (s->ids64 && s->precision == DIDI_PREC_BF16X3) DIDI_CHECK_ARG(s->cls_lo && s->x0_lo);
+    if (s->clamp_emb) DIDI_CHECK_ARG(s->ids64 && s->x0_hi && s->x0_lo);
     if (!shapes_ok(dec, s->B, s->S, s->C)) return DIDI_ERR_UNSUPPORTED;
     const size_t MH = (size_t)s->B * s->S * dec->H;
     const uint64_t ctr_per_draw = MH / 4;
@@ -201,6 +202,18 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
     f.workspace = s->workspace; f.workspace_bytes = s->workspace_bytes;
     f.x0_f32 = s->x0_f32;
     auto draw = [&](int i) -> const float* { return s->noise ? s->noise + (size_t)i * MH : nullptr; };
+    // per-step clamp extension: x0 <- emb[argmax(classifier(x0))]; the forward leaves x0 planes for the rounding GEMM
+    const bool clamp = s->clamp_emb != nullptr;
+    auto clamp_x0 = [&]() -> int {
+        int rc = didi_round_argmax(s->x0_hi, s->x0_lo, dec->H, s->cls_hi, s->cls_lo, dec->H, s->B * s->S, s->V, dec->H,
+                                   s->precision, s->argmax_partial, s->ids64, nullptr, stream);
+        if (rc != DIDI_OK) return rc;
+        return didi_embed_gather(s->ids64, s->clamp_emb, 1.0f, nullptr, s->B * s->S, s->S, dec->H, s->x0_f32, stream);
+    };
+    auto split_x0 = [&]() -> int {
+        return s->precision == DIDI_PREC_FP16 ? didi_split_fp16(s->x0_f32, s->x0_hi, s->x0_lo, MH, stream)
+                                              : didi_split_bf16(s->x0_f32, s->x0_hi, s->x0_lo, MH, stream);
+    };
     auto set_prof = [&](int k) {
         const bool on = s->prof_events_host && k == s->prof_call;
         f.prof_events_host = on ? s->prof_events_host : nullptr;
@@ -221,9 +234,13 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
             st.xin_out = s->xt_trace ? s->xt_trace + (size_t)k * MH : nullptr;
             set_prof(k);
             const bool last = k == s->n_calls - 1;
-            f.x0_hi = last ? s->x0_hi : nullptr;
-            f.x0_lo = last ? s->x0_lo : nullptr;
+            f.x0_hi = last || clamp ? s->x0_hi : nullptr;
+            f.x0_lo = last || clamp ? s->x0_lo : nullptr;
             TRY(didi_decoder_forward(dec, &f, stream));
+            if (clamp) {
+                TRY(clamp_x0());
+                if (last) TRY(split_x0());  // the final rounding reads the planes of the clamped x0
+            }
         }
     } else {
         didi_step_args init{};
@@ -246,9 +263,11 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
             st.x_out = s->x_state;
             st.t = s->time_row_host[k];
             st.xin_out = s->xt_trace ? s->xt_trace + (size_t)k * MH : nullptr;
-            f.x0_hi = nullptr; f.x0_lo = nullptr;
+            f.x0_hi = clamp ? s->x0_hi : nullptr;
+            f.x0_lo = clamp ? s->x0_lo : nullptr;
             set_prof(k);
             TRY(didi_decoder_forward(dec, &f, stream));
+            if (clamp) TRY(clamp_x0());
         }
         // final Euler update lands on sigma = 0 (src/sampling.py:80): x0 <- x + (x - x0_hat) * ratio
         didi_step_args fin{};
@@ -256,10 +275,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
         fin.X = s->x_state; fin.X0 = s->x0_f32; fin.ratio = s->c2_host[s->n_calls - 1]; fin.ce = 0.f; fin.cin = 1.0f;
         fin.x_out = s->x0_f32;
         TRY(didi_step_embed_ln(&fin, stream));
-        if (s->x0_hi) {
-            if (s->precision == DIDI_PREC_FP16) TRY(didi_split_fp16(s->x0_f32, s->x0_hi, s->x0_lo, MH, stream));
-            else TRY(didi_split_bf16(s->x0_f32, s->x0_hi, s->x0_lo, MH, stream));
-        }
+        if (s->x0_hi) TRY(split_x0());
     }
     if (s->ids64) {
         TRY(didi_round_argmax(s->x0_hi, s->x0_lo, dec->H, s->cls_hi, s->cls_lo, dec->H, s->B * s->S, s->V, dec->H,

@@ -25,6 +25,8 @@ Extra keyword-only arguments (all optional; defaults reproduce the reference cal
   trace   list      receives the denoiser input x_t of every call (fp32 [B,S,H], on device)
   return_ids        return (ids [B,S] int64, lengths [B] int32) instead of decoded strings
   philox_offset     first Philox counter of this call (didi_amd/dist.py gives every rank a disjoint range)
+  clamp             per-step clamp extension of BASELINE config 4 (NOT in the reference): after every denoiser
+                    call x0 <- emb[argmax(classifier(x0))] before the sampler update
 """
 import ctypes as C
 
@@ -56,7 +58,7 @@ def _host_arrays(plan, mode):
 
 @torch.no_grad()
 def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, max_len=-1, raw_output=False,
-           skip_special=True, *, noise=None, trace=None, return_ids=False, philox_offset=0, _prof=None):
+           skip_special=True, *, noise=None, trace=None, return_ids=False, philox_offset=0, clamp=False, _prof=None):
     if mode not in ("ddpm", "euler"):
         raise NotImplementedError(f"No {mode} sampling strategy")
     if not raw_output and not return_ids and tokenizer is None:
@@ -98,14 +100,14 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
 
     want_ids = not raw_output
     if isinstance(noise, str):
-        _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace)
+        _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp)
         if want_ids:
             x0_hi, x0_lo = ops.split(b["x0"].view(B * S, H), dtype=model._pd)
             ids = ops.round_argmax(x0_hi, x0_lo if model.precision == "bf16x3" else None, model._cls.hi, model._cls.lo,
                                    model.precision).view(B, S)
     else:
         xt_trace = torch.empty((n_calls, B, S, H), dtype=torch.float32, device=dev) if trace is not None else None
-        ids = torch.empty((B, S), dtype=torch.int64, device=dev) if want_ids else None
+        ids = torch.empty((B, S), dtype=torch.int64, device=dev) if want_ids or clamp else None
         rows, c0, c1, c2 = _host_arrays(plan, mode)
         a = _lib.SampleArgs()
         a.B, a.S, a.C, a.precision, a.euler, a.n_calls = B, S, Cn, model.prec, int(mode == "euler"), n_calls
@@ -118,9 +120,11 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
         a.workspace, a.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
         a.x_state, a.x0_f32 = b["x_state"].data_ptr(), b["x0"].data_ptr()
         a.x0_hi, a.x0_lo = b["x0_hi"].data_ptr(), b["x0_lo"].data_ptr()
-        if want_ids:
+        if want_ids or clamp:
             a.cls_hi, a.cls_lo, a.V = model._cls.hi.data_ptr(), model._cls.lo.data_ptr(), V
             a.argmax_partial, a.ids64 = b["partial"].data_ptr(), ids.data_ptr()
+        if clamp:
+            a.clamp_emb = model.emb.weight.data_ptr()
         if _prof is not None:  # bench.py: HIP events around the GEMM launches of one denoiser call
             a.prof_call, a.prof_events_host, a.prof_capacity = _prof.call, _prof.events, _prof.capacity
             a.prof_used_host = C.pointer(_prof.used)
@@ -143,11 +147,16 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
     return select_reply(replies)
 
 
-def _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace):
+def _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp=False):
     """Per-call loop with noise drawn by torch's device generator in the reference's order."""
     H = model.cfg.dec_dim
     dev = model.device
     x0 = b["x0"]
+
+    def clamp_x0():
+        hi, lo = ops.split(x0.view(B * S, H), dtype=model._pd)
+        ids = ops.round_argmax(hi, lo if model.precision == "bf16x3" else None, model._cls.hi, model._cls.lo, model.precision)
+        x0.copy_(ops.embed_gather(ids.view(B, S), model.emb.weight))
     noise = torch.randn((B, S, H), dtype=torch.float32, device=dev)  # sampling.py:13
 
     def forward(step_kw, t):
@@ -165,6 +174,8 @@ def _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace):
         fa.workspace, fa.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
         fa.x0_f32 = x0.data_ptr()
         _lib.check(lib.didi_decoder_forward(C.byref(model._dec), C.byref(fa), _lib.current_stream()), "decoder_forward")
+        if clamp:
+            clamp_x0()
         if trace is not None:
             trace.append(xin)
 

@@ -319,6 +319,11 @@ typedef struct didi_sample_args {
     void** prof_events_host;
     int prof_capacity;
     int* prof_used_host;
+    /* optional per-step clamp (BASELINE config 4; NOT in the reference, which never clamps): when
+     * clamp_emb != NULL (fp32 [V, H], `emb.weight`), every denoiser output is replaced by the embedding
+     * row of its rounded token, x0 <- emb[argmax(classifier(x0))], before the sampler update.  Needs the
+     * rounding fields above (cls_*, V, argmax_partial, ids64 as scratch, x0_hi/x0_lo). */
+    const float* clamp_emb;
 } didi_sample_args;
 int didi_sample(const didi_decoder* dec, const didi_sample_args* a, void* stream);
 

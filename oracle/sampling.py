@@ -7,6 +7,8 @@ inject the exact stream captured from a reference run.  Draw ORDER and COUNT are
 reference's: one initial draw, then one per loop iteration (ddpm) or one per loop iteration
 plus one for the final step (euler, drawn even when s_churn == 0).
 ``trace`` (optional list) receives the model INPUT x_t of every denoiser call, in call order.
+``clamp=True`` is the per-step clamp EXTENSION of BASELINE config 4 (not in the reference, which never
+clamps): every denoiser output is replaced by emb[argmax(classifier(x0))] before the sampler update.
 TEST INFRASTRUCTURE: see oracle/__init__.py.
 """
 import torch
@@ -38,15 +40,16 @@ def sample(
     skip_special=True,
     noise_source=default_noise_source,
     trace=None,
+    clamp=False,
 ):
     emb = model.emb(raw_context.input_ids)[:, :max_len]  # sampling.py:11 (default -1 drops the last position)
     shape = tuple(emb.shape)
     x_t = noise_source(shape) * model.sigmas[-1] * noise_factor**2  # sampling.py:13
     ones = torch.ones((shape[0], 1), dtype=torch.long)
     if mode == "ddpm":
-        logits = sample_ddpm(model, x_t, raw_context, ones, step_freq, noise_source, trace)
+        logits = sample_ddpm(model, x_t, raw_context, ones, step_freq, noise_source, trace, clamp)
     elif mode == "euler":
-        logits = sample_euler(model, x_t, raw_context, ones, step_freq, noise_source, trace)
+        logits = sample_euler(model, x_t, raw_context, ones, step_freq, noise_source, trace, clamp)
     else:
         raise NotImplementedError(f"No {mode} sampling strategy")
     if raw_output:
@@ -58,7 +61,11 @@ def sample(
     return tokenizer.batch_decode(truncate_predictions(predictions, eos_id), skip_special_tokens=skip_special)
 
 
-def sample_ddpm(model, x_t, raw_context, ones, step_freq, noise_source, trace=None):
+def _clamp(model, x_0):
+    return model.emb(model.classifier(x_0).argmax(-1))
+
+
+def sample_ddpm(model, x_t, raw_context, ones, step_freq, noise_source, trace=None, clamp=False):
     # sampling.py:38-65
     T = model.diffusion_steps
     x_t = scale_input(x_t, model.sigmas[-1])
@@ -73,6 +80,8 @@ def sample_ddpm(model, x_t, raw_context, ones, step_freq, noise_source, trace=No
             time_ids=t * ones,
             context=ctx,
         )
+        if clamp:
+            x_0 = _clamp(model, x_0)
         sigma_t = model.sigmas[max(t - step_freq, 1)]
         noise = noise_source(tuple(x_t.shape))
         x_t = scale_input(x_0 + sigma_t * noise, sigma_t)
@@ -85,10 +94,12 @@ def sample_ddpm(model, x_t, raw_context, ones, step_freq, noise_source, trace=No
         time_ids=ones,
         context=ctx,
     )
+    if clamp:
+        x_0 = _clamp(model, x_0)
     return model.classifier(x_0)
 
 
-def euler_step(model, x_t, sigma_t, raw_context, ctx, next_t, num_sigmas, ones, noise, trace=None):
+def euler_step(model, x_t, sigma_t, raw_context, ctx, next_t, num_sigmas, ones, noise, trace=None, clamp=False):
     # sampling.py:86-101
     x_t, sigma_hat = get_euler_variables(x_t, noise, sigma_t, model.s_churn, model.s_tmin, model.s_tmax, num_sigmas)
     t_hat = (model.sigmas - sigma_hat).abs().argmin()
@@ -102,12 +113,14 @@ def euler_step(model, x_t, sigma_t, raw_context, ctx, next_t, num_sigmas, ones, 
         time_ids=t_hat * ones,
         context=ctx,
     )
+    if clamp:
+        x_0 = _clamp(model, x_0)
     d = (x_t - x_0) / sigma_hat
     dt = model.sigmas[next_t] - sigma_hat
     return x_t + d * dt, ctx
 
 
-def sample_euler(model, x_t, raw_context, ones, step_freq, noise_source, trace=None):
+def sample_euler(model, x_t, raw_context, ones, step_freq, noise_source, trace=None, clamp=False):
     # sampling.py:68-83
     T = model.diffusion_steps
     timesteps = range(T, 1, -step_freq)
@@ -116,10 +129,10 @@ def sample_euler(model, x_t, raw_context, ones, step_freq, noise_source, trace=N
     for t in timesteps:
         noise = noise_source(tuple(x_t.shape))
         x_t, ctx = euler_step(
-            model, x_t, model.sigmas[t], raw_context, ctx, max(t - step_freq, 1), num_sigmas, ones, noise, trace
+            model, x_t, model.sigmas[t], raw_context, ctx, max(t - step_freq, 1), num_sigmas, ones, noise, trace, clamp
         )
     noise = noise_source(tuple(x_t.shape))
-    x_0, _ = euler_step(model, x_t, model.sigmas[1], raw_context, ctx, 0, num_sigmas, ones, noise, trace)
+    x_0, _ = euler_step(model, x_t, model.sigmas[1], raw_context, ctx, 0, num_sigmas, ones, noise, trace, clamp)
     return model.classifier(x_0)
 
 

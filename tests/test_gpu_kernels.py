@@ -255,7 +255,7 @@ def test_gemm_rejects_bad_shapes(ops):
 
 
 # ------------------------------------------------------------------ rounding (classifier + argmax)
-@pytest.mark.parametrize("M,V,K", [(184, 8008, 128), (77, 600, 128), (300, 8008, 768), (5, 130, 64)])
+@pytest.mark.parametrize("M,V,K", [(184, 8008, 128), (77, 600, 128), (300, 8008, 768), (5, 130, 64), (168, 50000, 768)])
 @pytest.mark.parametrize("precision", ALL_PREC)
 def test_round_argmax(ops, M, V, K, precision):
     x, w = rnd(M, K, seed=11), rnd(V, K, seed=12, scale=0.02)

@@ -114,6 +114,40 @@ def test_reference_shaped_loop_drives_the_hip_model():
         model(decoder_inputs_embeds=trace[0], time_ids=torch.ones(4, 1, dtype=torch.long))
 
 
+@pytest.mark.parametrize("name", ["tiny_ddpm_f1", "tiny_euler_f2"])
+def test_per_step_clamp_extension_matches_oracle(name):
+    """BASELINE config 4's per-step clamp x0 <- emb[argmax(classifier(x0))] (an extension: the reference never
+    clamps, so this is checked against the oracle's restatement of the same rule -- parity unpinned by the reference)."""
+    from didi_amd.sampling import sample
+    from golden_util import spec_to_oracle_config
+    from oracle.model import OracleDiDi
+    from oracle.sampling import Context, sample as oracle_sample
+
+    t, meta = load_case(name)
+    run = meta["run"]
+    w = weights_of(load_case("tiny_weights")[0])
+    draws = noise_list(t, int(meta["n_noise"]))
+    want_trace = []
+    want = oracle_sample(Context(t["in.input_ids"], t["in.attention_mask"]), OracleDiDi(w, spec_to_oracle_config(meta["spec"])),
+                         run["mode"], run["step_freq"], max_len=run["max_len"], raw_output=True, noise_source=ListNoise(draws),
+                         trace=want_trace, clamp=True)
+    ctx = _ctx(t["in.input_ids"], t["in.attention_mask"])
+    for precision, bar in (("bf16x3", 0.999), ("fp16", 0.97)):
+        model = _model(w, spec_to_config(meta["spec"]), precision)
+        trace = []
+        ids, _ = sample(ctx, model, run["mode"], run["step_freq"], max_len=run["max_len"], noise=torch.stack(draws),
+                        return_ids=True, trace=trace, clamp=True)
+        match = (ids.cpu() == want.argmax(-1)).float().mean().item()
+        worst = max(rel_l2(a, b) for a, b in zip(trace, want_trace))
+        print(f"\n[clamp {name} {precision}] id match {match:.4f}  max x_t rel-L2 {worst:.3e}")
+        assert match >= bar
+        if precision == "bf16x3":
+            assert worst <= 1e-4
+        logits = sample(ctx, model, run["mode"], run["step_freq"], max_len=run["max_len"], noise=torch.stack(draws),
+                        raw_output=True, clamp=True)
+        assert torch.equal(logits.argmax(-1).cpu(), ids.cpu()) or precision != "bf16x3"
+
+
 def test_sample_errors_and_decode():
     from didi_amd.sampling import sample, truncate_predictions
 

@@ -1,28 +1,31 @@
-// MFMA bf16 GEMM for the decoder's Linear layers and the rounding (classifier + argmax) step.
+// MFMA GEMM for the decoder's Linear layers and the rounding (classifier + argmax) step.
 //
-//   C[M,N] = epilogue( A[M,K] * W[N,K]^T )      fp32 accumulate, operands as bf16 split planes
+//   C[M,N] = epilogue( A[M,K] * W[N,K]^T )      fp32 accumulate, operands as split 16-bit planes
 //
-// Tile: 128(M) x 128(N) per 256-thread workgroup; 4 waves as 2(M) x 2(N), each wave a 64x64
-// sub-tile = 4x4 v_mfma_f32_16x16x32_bf16 accumulators.  The MFMA is issued "swapped"
-// (A-operand = weight rows, B-operand = activation rows) so that every lane ends up holding FOUR
-// CONSECUTIVE OUTPUT COLUMNS n of one output row m: the epilogue then loads bias as one float4 and
-// stores 8-byte bf16 packs / 16-byte fp32 vectors instead of scalars.
+// Precisions: bf16 / fp16 (one product on the hi planes, v_mfma_f32_16x16x32_{bf16,f16}) and bf16x3
+// (lo*hi + hi*lo + hi*hi on bf16 planes, fused into one K-loop).  Kernels, by shape:
+//   gemm_pp_kernel   256(M) x 192(N) tile, 8 waves in two staggered groups      M >= 2048 (the sampler's
+//                    (the fast path: see its header further down)                 B*S = 16384 rows)
+//   gemm_big_kernel  same tile, in-phase K-loop (A/B baseline, DIDI_GEMM_PP=0; MT=2: 128 x 192, 4 waves)
+//   gemm_kernel      128 x 128 tile, 4 waves (2 x 2 of 64 x 64)                   small M, odd N
+//   tile_regstage    register-staged fallback inside gemm_kernel                  K not a multiple of the K-tile
+//   gemm_argmax_kernel  128-row tiles over vocabulary chunks, running (max, index), logits never written
+// The MFMA is issued "swapped" (A-operand = weight rows, B-operand = activation rows) so that every
+// lane ends up holding CONSECUTIVE OUTPUT COLUMNS n of one output row m: the epilogue then loads
+// bias as float4s and stores 8/16-byte plane packs and 16-byte fp32 vectors instead of scalars.
 //
-// Main loop (tile_glds): operand tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no
-// staging registers, no ds_write -- the register-staged first version of this kernel was bound by
-// ds_write_b128 issue, profiles/r01_v1_*), two LDS stages of 32 KiB, the DMA of K-tile t+1 in
-// flight while K-tile t is multiplied, one barrier per K-tile.
-//   precision bf16   : K-tile 64;  stage = {A_hi, W_hi} tiles of [128 rows][128 B]
-//   precision bf16x3 : K-tile 32;  stage = {A_hi, A_lo, W_hi, W_lo} tiles of [128 rows][64 B]; the
-//                      three products lo*hi, hi*lo, hi*hi are issued from ONE staging of the four
-//                      tiles (48 MFMAs per 16 fragment reads) instead of three trips over K.
+// LDS-DMA main loops: operand tiles go HBM/L2 -> LDS by global_load_lds_dwordx4 (no staging
+// registers, no ds_write -- the register-staged first version of this kernel was bound by
+// ds_write_b128 issue, profiles/r01_v1_*), two LDS stages, counted vmcnt + raw s_barrier.
+//   one product : K-tile 64;  stage = {A, W} tiles of [rows][128 B]
+//   bf16x3      : K-tile 32;  stage = {A_hi, A_lo, W_hi, W_lo} tiles of [rows][64 B]; the three
+//                 products are issued from ONE staging of the four tiles (72 MFMAs per 20 fragment
+//                 reads per wave in the big tile) instead of three trips over K.
 // LDS image: an LDS-DMA instruction writes 1 KiB = lane-linear 16-byte slots, so the bank-conflict
 // swizzle is applied to the per-lane SOURCE address and again on the fragment read
 // (cdna_hip_programming.md rule 21): slot s of row r holds k-chunk s ^ f(r), with
 // f(r) = r & 7 for 128-byte rows and f(r) = (-(r >> 2)) & 3 for 64-byte rows; both make every
 // 16-lane ds_read_b128 group hit 16 distinct 16-byte slots of the 256-byte bank row.
-// tile_regstage is the generic fallback (K not a multiple of the K-tile): register staging with
-// zero-fill past K, three passes over K for bf16x3.
 //
 // Grid: 1-D, XCD-aware: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs,
 // so id -> (id % 8) * chunk + id / 8 gives each XCD (private 4 MiB L2) a contiguous band of output

@@ -80,6 +80,8 @@ __global__ void __launch_bounds__(512, 2) lab_kernel(P p) {
     const int lr = lane & 15, lg = lane >> 4;
     const int grp = wave >> 2, w4 = wave & 3;  // waves w and w+4 share a SIMD
 
+    const unsigned long long t_start = (V == 9) ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long t_loop0 = 0, t_loop1 = 0;
     f32x4 acc[6][4];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -175,6 +177,7 @@ __global__ void __launch_bounds__(512, 2) lab_kernel(P p) {
         else { ISSUE_N(0, 0, 8); if (nt > 1) ISSUE_N(1, 1, 8); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (V == 9) t_loop0 = __builtin_amdgcn_s_memtime();
         if (grp == 0) {
             for (int i = 0; i < nt; ++i) {
                 if (V == 9) c0 = __builtin_amdgcn_s_memtime();
@@ -228,9 +231,10 @@ __global__ void __launch_bounds__(512, 2) lab_kernel(P p) {
             MFMA_RANGE(0, 0, 6)
             MFMA_RANGE(1, 0, 6)
         }
+        if (V == 9) t_loop1 = __builtin_amdgcn_s_memtime();
         if (V == 9 && lane == 0 && w4 == 0) {
-            unsigned long long* o = p.stamps + (size_t)blockIdx.x * 6 + grp * 3;
-            o[0] = sA; o[1] = sB; o[2] = sC;
+            unsigned long long* o = p.stamps + (size_t)blockIdx.x * 12 + grp * 6;
+            o[0] = sA; o[1] = sB; o[2] = sC; o[3] = t_loop0 - t_start; o[4] = t_loop1 - t_loop0;
         }
     }
 
@@ -244,6 +248,10 @@ __global__ void __launch_bounds__(512, 2) lab_kernel(P p) {
             if (n >= p.N) continue;
             *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.N + n) = acc[ni][mi];
         }
+    }
+    if (V == 9) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores acknowledged
+        if (lane == 0 && w4 == 0) p.stamps[(size_t)blockIdx.x * 12 + grp * 6 + 5] = __builtin_amdgcn_s_memtime() - t_loop1;
     }
 }
 
@@ -297,7 +305,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&da, a.size() * 2)); CK(hipMalloc(&dw, w.size() * 2));
         CK(hipMalloc(&c0, (size_t)M * N * 4)); CK(hipMalloc(&c1, (size_t)M * N * 4));
         const int grid = M / BMM * (N / BNN);
-        CK(hipMalloc(&stamps, grid * 6 * 8));
+        CK(hipMalloc(&stamps, grid * 12 * 8));
         CK(hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice));
         P p{M, N, K, N / BNN, da, dw, c0, stamps};
@@ -318,13 +326,15 @@ int main(int argc, char** argv) {
         check("v8 3-slot staggered", run<8>(p, iters, st));
         check("v9 = v8 + stamps", run<9>(p, iters, st));
         {
-            std::vector<unsigned long long> h(grid * 6);
+            std::vector<unsigned long long> h(grid * 12);
             CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
-            double x[6] = {0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < grid; ++i) for (int j = 0; j < 6; ++j) x[j] += (double)h[i * 6 + j];
+            double x[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < grid; ++i) for (int j = 0; j < 12; ++j) x[j] += (double)h[i * 12 + j];
             const double nt = K / BKK;
             printf("      v9 per K-tile: X  A %.0f  B1 %.0f  B2 %.0f | Y  A %.0f  B1 %.0f  B2 %.0f\n", x[0] / grid / nt, x[1] / grid / nt,
-                   x[2] / grid / nt, x[3] / grid / nt, x[4] / grid / nt, x[5] / grid / nt);
+                   x[2] / grid / nt, x[6] / grid / nt, x[7] / grid / nt, x[8] / grid / nt);
+            printf("      v9 per workgroup (ticks): X prologue %.0f loop %.0f epilogue %.0f | Y prologue %.0f loop %.0f epilogue %.0f\n",
+                   x[3] / grid, x[4] / grid, x[5] / grid, x[9] / grid, x[10] / grid, x[11] / grid);
         }
         fflush(stdout);
         CK(hipFree(da)); CK(hipFree(dw)); CK(hipFree(c0)); CK(hipFree(c1)); CK(hipFree(stamps));

@@ -148,6 +148,51 @@ def test_per_step_clamp_extension_matches_oracle(name):
         assert torch.equal(logits.argmax(-1).cpu(), ids.cpu()) or precision != "bf16x3"
 
 
+@pytest.mark.parametrize("B,C,max_len", [(1, 2, -1), (1, 1, 1), (3, 96, 96), (2, 96, -1), (5, 33, 7)])
+def test_edge_shapes_against_oracle(B, C, max_len):
+    """Smallest (one dialog, one target position), largest supported (S = C = 96) and ragged shapes, contexts with a
+    single visible token, against the CPU oracle with the same synthetic weights and injected noise."""
+    from didi_amd.config import DiDiConfig
+    from didi_amd.sampling import _target_len, sample
+    from didi_amd.synthetic import synthetic_state_dict
+    from oracle.model import OracleDiDi
+    from oracle.sampling import Context, sample as oracle_sample
+
+    cfg = DiDiConfig(vocab=300, dec_dim=128, dec_layers=2, dec_heads=4, dec_ffn=256, dec_max_pos=128, enc_dim=96, enc_layers=1,
+                     enc_heads=4, enc_ffn=192, enc_max_pos=128, diffusion_steps=6)
+    sd = synthetic_state_dict(cfg, seed=77)
+    g = torch.Generator().manual_seed(B * 100 + C)
+    ids = torch.randint(3, cfg.vocab, (B, C), generator=g)
+    mask = torch.ones(B, C, dtype=torch.long)
+    mask[0, 1:] = 0  # one dialog whose context is a single token
+    S = _target_len(C, max_len)
+    draws = [torch.randn(B, S, cfg.dec_dim, generator=g) for _ in range(cfg.diffusion_steps + 1)]
+    want = oracle_sample(Context(ids, mask), OracleDiDi(sd, config_to_oracle_config(cfg)), "ddpm", 1, max_len=max_len,
+                         raw_output=True, noise_source=ListNoise(draws))
+    n_calls = len(range(cfg.diffusion_steps, 1, -1)) + 1
+    model = _model(sd, cfg, "bf16x3")
+    got = sample(_ctx(ids, mask), model, "ddpm", 1, max_len=max_len, raw_output=True, noise=torch.stack(draws[:n_calls]))
+    assert tuple(got.shape) == (B, S, cfg.vocab)
+    assert rel_l2(got, want) <= 1e-4
+    assert (got.argmax(-1).cpu() == want.argmax(-1)).float().mean().item() >= 0.999
+
+
+def test_unsupported_lengths_fail_loudly():
+    from didi_amd._lib import DidiHipError
+    from didi_amd.config import DiDiConfig
+    from didi_amd.sampling import sample
+    from didi_amd.synthetic import synthetic_state_dict
+
+    cfg = DiDiConfig(vocab=300, dec_dim=128, dec_layers=1, dec_heads=4, dec_ffn=256, dec_max_pos=128, enc_dim=96, enc_layers=1,
+                     enc_heads=4, enc_ffn=192, enc_max_pos=128, diffusion_steps=4)
+    model = _model(synthetic_state_dict(cfg, seed=78), cfg, "fp16")
+    ids = torch.randint(3, cfg.vocab, (2, 100))
+    with pytest.raises(DidiHipError):  # context of 100 tokens: the attention kernels are built for <= 96
+        sample(_ctx(ids, torch.ones_like(ids)), model, "ddpm", 1, raw_output=True)
+    with pytest.raises(ValueError):  # max_len = 0 leaves no target position
+        sample(_ctx(ids[:, :8], torch.ones_like(ids[:, :8])), model, "ddpm", 1, max_len=0, raw_output=True)
+
+
 def test_sample_errors_and_decode():
     from didi_amd.sampling import sample, truncate_predictions
 

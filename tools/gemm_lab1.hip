@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(512, 2) lab_kernel(P p) {
     // V0: wave issues q = wave + 8j (j < 7).  V5: group X issues q = w4 + 4j (j < 14).
     // V8: group Y issues the A pieces q = w4 + 4j (j < 8), group X the W pieces q = 32 + w4 + 4j (j < 6).
     constexpr int NP = V == 0 ? 7 : (V == 5 ? 14 : 8);
+    constexpr int SPL = V == 10 ? 6 : (V == 11 ? 2 : (V == 12 ? 5 : 4));  // weight fragments of k-step 0 multiplied in slot B1
     const u16* src[NP];
     int qoff[NP];
 #pragma unroll
@@ -189,11 +190,11 @@ __global__ void __launch_bounds__(512, 2) lab_kernel(P p) {
                 __builtin_amdgcn_s_barrier();  // end A_i
                 if (V == 9) c1 = __builtin_amdgcn_s_memtime();
                 __builtin_amdgcn_s_setprio(1);
-                MFMA_RANGE(0, 0, 4)
+                MFMA_RANGE(0, 0, SPL)
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();  // end B1_i
                 if (V == 9) c2 = __builtin_amdgcn_s_memtime();
-                MFMA_RANGE(0, 4, 6)
+                MFMA_RANGE(0, SPL, 6)
                 MFMA_RANGE(1, 0, 6)
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -325,6 +326,10 @@ int main(int argc, char** argv) {
         check("v5 staggered, X issues", run<5>(p, iters, st));
         check("v8 3-slot staggered", run<8>(p, iters, st));
         check("v9 = v8 + stamps", run<9>(p, iters, st));
+        check("v10 B1 = 24 MFMAs", run<10>(p, iters, st));
+        check("v11 B1 = 8 MFMAs", run<11>(p, iters, st));
+        check("v12 B1 = 20 MFMAs", run<12>(p, iters, st));
+        check("v8 again", run<8>(p, iters, st));
         {
             std::vector<unsigned long long> h(grid * 12);
             CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));

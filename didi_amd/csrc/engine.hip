@@ -9,10 +9,13 @@
 //                                 cross-attention query buffer once self-attention is done
 //   att planes [2][M][H]   bf16   attention output (concatenated heads)
 //   ffn planes [2][M][I]   bf16   GELU(FFN-up)
-//   tmp        [M][H]      fp32   pre-LayerNorm sum (dense + bias + residual)
+//   tmp        [M][H]      fp32   pre-LayerNorm sum (dense + bias + residual); unused when the fused
+//                                 projection+LayerNorm kernel takes the shape
+//   ln_stats                      row-statistic granules of the fused kernel (zeroed once per call, epochs 1..3L)
 // didi_decoder_prepare_context uses the front of the same buffer for the context planes.
 #include <algorithm>
 
+#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -20,6 +23,8 @@ namespace {
 struct Carve {
     u16 *h_hi, *h_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *ffn_hi, *ffn_lo;
     float* tmp;
+    void* ln_stats;
+    size_t ln_stats_bytes;
     size_t total;
 };
 
@@ -39,6 +44,8 @@ Carve carve(const didi_decoder* d, int B, int S, char* base) {
     c.ffn_hi = (u16*)take(M * I * 2);
     c.ffn_lo = (u16*)take(M * I * 2);
     c.tmp = (float*)take(M * H * 4);
+    c.ln_stats_bytes = didi_gemm_ln_stats_bytes((int)M);
+    c.ln_stats = take(c.ln_stats_bytes);
     c.total = o;
     return c;
 }
@@ -73,6 +80,32 @@ int gemm(const didi_linear& w, int precision, int M, const u16* a_hi, const u16*
     const int rc = didi_gemm_bf16(&g, stream);
     if (prof) prof->mark(stream);
     return rc;
+}
+
+// output projection + residual + LayerNorm: the fused kernel where it supports the shape (H = 768, M >= 2048),
+// else GEMM -> fp32 tmp -> LayerNorm.  `epoch` tags this launch's statistics in the shared `stats` buffer.
+int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi, const u16* a_lo, int lda, const u16* r_hi,
+            const u16* r_lo, int ldr, float* tmp, void* stats, uint32_t epoch, const float* gamma, const float* beta, float eps,
+            u16* y_hi, u16* y_lo, float* y_f32, void* stream, Prof* prof) {
+    static const bool fuse = [] {  // DIDI_GEMM_LN=0: A/B switch back to GEMM + LayerNorm
+        const char* e = getenv("DIDI_GEMM_LN");
+        return !(e && e[0] == '0');
+    }();
+    if (fuse && didi_gemm_ln_supported(M, w.N, w.K, precision) && w.bias) {
+        didi_gemm_args g{};
+        g.M = M; g.N = w.N; g.K = w.K; g.precision = precision;
+        g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
+        g.W_hi = w.w_hi; g.W_lo = w.w_lo; g.ldw = w.K;
+        g.bias = w.bias; g.act = DIDI_ACT_NONE;
+        g.R_hi = r_hi; g.R_lo = r_lo; g.ldr = ldr;
+        if (prof) prof->mark(stream);
+        const int rc = didi_gemm_ln(&g, gamma, beta, eps, y_hi, y_lo, y_f32, stats, epoch, stream);
+        if (prof) prof->mark(stream);
+        return rc;
+    }
+    int rc = gemm(w, precision, M, a_hi, a_lo, lda, DIDI_ACT_NONE, r_hi, r_lo, ldr, tmp, nullptr, nullptr, w.N, stream, prof);
+    if (rc != DIDI_OK) return rc;
+    return didi_layernorm(tmp, gamma, beta, eps, M, w.N, y_hi, y_lo, y_f32, fmt, stream);
 }
 
 }  // namespace
@@ -140,6 +173,9 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
     st.ln_gamma = dec->emb_ln_g; st.ln_beta = dec->emb_ln_b; st.ln_eps = dec->ln_eps;
     st.h_hi = w.h_hi; st.h_lo = w.h_lo; st.plane_format = fmt;
     TRY(didi_step_embed_ln(&st, stream));
+    // statistic granules of the fused projection+LayerNorm launches: cleared once, then one epoch per launch
+    if (hipMemsetAsync(w.ln_stats, 0, w.ln_stats_bytes, as_stream(stream)) != hipSuccess) return DIDI_ERR_LAUNCH;
+    uint32_t epoch = 0;
 
     for (int l = 0; l < dec->L; ++l) {
         const didi_decoder_layer& ly = dec->layers_host[l];
@@ -155,8 +191,8 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.V_hi = w.qkv_hi + 2 * H; at.V_lo = x3 ? w.qkv_lo + 2 * H : nullptr; at.ldv = 3 * H;
         at.O_hi = w.att_hi; at.O_lo = x3 ? w.att_lo : nullptr; at.ldo = H;
         TRY(didi_attention(&at, stream));
-        TRY(gemm(ly.attn_out, prec, M, w.att_hi, w.att_lo, H, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream, &prof));
-        TRY(didi_layernorm(w.tmp, ly.ln1_g, ly.ln1_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, fmt, stream));
+        TRY(gemm_ln(ly.attn_out, prec, fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln1_g, ly.ln1_b,
+                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof));
         // --- cross-attention block (K/V hoisted: didi_decoder_prepare_context)
         u16* q_hi = w.qkv_hi;
         u16* q_lo = x3 ? w.qkv_lo : nullptr;
@@ -167,19 +203,15 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.K_hi = a->kv_hi + kvoff; at.K_lo = x3 ? a->kv_lo + kvoff : nullptr; at.ldk = 2 * H;
         at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;
         TRY(didi_attention(&at, stream));
-        TRY(gemm(ly.cross_out, prec, M, w.att_hi, w.att_lo, H, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream, &prof));
-        TRY(didi_layernorm(w.tmp, ly.ln2_g, ly.ln2_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, fmt, stream));
+        TRY(gemm_ln(ly.cross_out, prec, fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln2_g, ly.ln2_b,
+                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof));
         // --- feed-forward block
         TRY(gemm(ly.ffn_up, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_GELU, nullptr, nullptr, 0, nullptr, w.ffn_hi,
                  x3 ? w.ffn_lo : nullptr, I, stream, &prof));
-        TRY(gemm(ly.ffn_down, prec, M, w.ffn_hi, w.ffn_lo, I, DIDI_ACT_NONE, w.h_hi, w.h_lo, H, w.tmp, nullptr, nullptr, H, stream, &prof));
-        if (!last) {
-            TRY(didi_layernorm(w.tmp, ly.ln3_g, ly.ln3_b, dec->ln_eps, M, H, w.h_hi, w.h_lo, nullptr, fmt, stream));
-        } else {
-            u16* o_hi = a->x0_hi ? a->x0_hi : w.h_hi;
-            u16* o_lo = a->x0_hi ? a->x0_lo : w.h_lo;
-            TRY(didi_layernorm(w.tmp, ly.ln3_g, ly.ln3_b, dec->ln_eps, M, H, o_hi, o_lo, a->x0_f32, fmt, stream));
-        }
+        u16* o_hi = last && a->x0_hi ? a->x0_hi : w.h_hi;
+        u16* o_lo = last && a->x0_hi ? a->x0_lo : w.h_lo;
+        TRY(gemm_ln(ly.ffn_down, prec, fmt, M, w.ffn_hi, w.ffn_lo, I, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln3_g, ly.ln3_b,
+                    dec->ln_eps, o_hi, o_lo, last ? a->x0_f32 : nullptr, stream, &prof));
     }
     if (a->prof_used_host) *a->prof_used_host = prof.used;
     return DIDI_OK;

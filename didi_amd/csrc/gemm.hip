@@ -33,6 +33,8 @@
 // matrix (<= 4.7 MB) stays L2-resident.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.hpp"
 
 #define BM 128
@@ -60,6 +62,11 @@ struct GemmParams {
     // argmax variant
     int tiles_m, tiles_n, nchunks, tiles_per_chunk;
     float2* partial;  // [M][nchunks] (value, index bits)
+    // fused LayerNorm epilogue (gemm_pp_kernel<.., LN = true>): y = LayerNorm(acc + bias + residual) -> C_*
+    const float *ln_gamma, *ln_beta;
+    float ln_eps;
+    unsigned long long* ln_stats;  // [tiles_m][tiles_n][256][2] granules {epoch, bits} of each tile's per-row (sum, M2)
+    unsigned ln_epoch;             // tag of this launch's granules (>= 1; older tags and zero are stale)
 };
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
@@ -581,7 +588,7 @@ __global__ void __launch_bounds__(BigGeom<MT>::THREADS, 2) gemm_big_kernel(GemmP
 //                                                                   into buffer i&1, waits for A(i+1)
 // The activation pieces (the ones that can miss L2) get 1.5 K-tiles of flight, the weight pieces
 // (L2 hits) one; every DMA wait is a counted vmcnt followed by a barrier before the first read.
-template <int NPASS, bool F16>
+template <int NPASS, bool F16, bool LN>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     using G = BigGeom<4>;
     constexpr int BKK = NPASS == 3 ? 32 : 64;
@@ -743,32 +750,187 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     // residual planes: all 12 loads of half a wave tile are issued before the first use (the fragment
     // registers are dead by now), instead of one exposed memory round trip per 8 columns
     const int pre = p.R_hi != nullptr && p.R_f32 == nullptr;
+    if constexpr (!LN) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        uint4 rh[2][3], rl[2][3];
+        for (int half = 0; half < 2; ++half) {
+            uint4 rh[2][3], rl[2][3];
 #pragma unroll
-        for (int mj = 0; mj < 2; ++mj)
+            for (int mj = 0; mj < 2; ++mj)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                rh[mj][k] = uint4{0, 0, 0, 0};
-                rl[mj][k] = uint4{0, 0, 0, 0};
-                const int m = m0 + wm * 64 + (half * 2 + mj) * 16 + lr;
-                const int n = n0 + wn * 96 + 32 * k + 8 * lg;
-                if (pre && m < p.M && n + 8 <= p.N) {
-                    rh[mj][k] = *reinterpret_cast<const uint4*>(p.R_hi + (size_t)m * p.ldr + n);
-                    if (p.R_lo) rl[mj][k] = *reinterpret_cast<const uint4*>(p.R_lo + (size_t)m * p.ldr + n);
+                for (int k = 0; k < 3; ++k) {
+                    rh[mj][k] = uint4{0, 0, 0, 0};
+                    rl[mj][k] = uint4{0, 0, 0, 0};
+                    const int m = m0 + wm * 64 + (half * 2 + mj) * 16 + lr;
+                    const int n = n0 + wn * 96 + 32 * k + 8 * lg;
+                    if (pre && m < p.M && n + 8 <= p.N) {
+                        rh[mj][k] = *reinterpret_cast<const uint4*>(p.R_hi + (size_t)m * p.ldr + n);
+                        if (p.R_lo) rl[mj][k] = *reinterpret_cast<const uint4*>(p.R_lo + (size_t)m * p.ldr + n);
+                    }
+                }
+#pragma unroll
+            for (int mj = 0; mj < 2; ++mj) {
+                const int mi = half * 2 + mj;
+                const int m = m0 + wm * 64 + mi * 16 + lr;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int n = n0 + wn * 96 + 32 * k + 8 * lg;
+                    if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi], gelu_tbl, pre, rh[mj][k], rl[mj][k]);
+                    else if (n < p.N) epilogue4(p, m, n, acc[2 * k][mi][0], acc[2 * k][mi][1], acc[2 * k][mi][2], acc[2 * k][mi][3]);
                 }
             }
+        }
+    } else {
+        // ---- fused LayerNorm: the tiles_n (= 4) workgroups of a 256-row band each hold 192 of the 768 columns
+        // of every row.  Each computes exact local row statistics (sum, M2 about its local mean), publishes them,
+        // collects its band mates', combines the four partials (Chan's formula) and normalises its own slice
+        // from registers: the pre-norm tensor never goes to memory.  Host side: a launch holds at most one
+        // workgroup per CU, so all mates are co-resident; the wait is bounded anyway.
+        float* red = reinterpret_cast<float*>(smem);          // [2 wn][256 rows] partial sums
+        float* red2 = red + 512;                              // [2 wn][256 rows] partial M2
+        float2* mr = reinterpret_cast<float2*>(red2 + 512);   // [256] (mean, rstd)
+        // 1. v = acc + bias + residual, in place
 #pragma unroll
-        for (int mj = 0; mj < 2; ++mj) {
-            const int mi = half * 2 + mj;
-            const int m = m0 + wm * 64 + mi * 16 + lr;
-            if (m >= p.M) continue;
+        for (int half = 0; half < 2; ++half) {
+            uint4 rh[2][3], rl[2][3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int n = n0 + wn * 96 + 32 * k + 8 * lg;
-                if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi], gelu_tbl, pre, rh[mj][k], rl[mj][k]);
-                else if (n < p.N) epilogue4(p, m, n, acc[2 * k][mi][0], acc[2 * k][mi][1], acc[2 * k][mi][2], acc[2 * k][mi][3]);
+            for (int mj = 0; mj < 2; ++mj)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int m = min(m0 + wm * 64 + (half * 2 + mj) * 16 + lr, p.M - 1);
+                    const int n = n0 + wn * 96 + 32 * k + 8 * lg;
+                    rh[mj][k] = *reinterpret_cast<const uint4*>(p.R_hi + (size_t)m * p.ldr + n);
+                    rl[mj][k] = *reinterpret_cast<const uint4*>(p.R_lo + (size_t)m * p.ldr + n);
+                }
+#pragma unroll
+            for (int mj = 0; mj < 2; ++mj) {
+                const int mi = half * 2 + mj;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int n = n0 + wn * 96 + 32 * k + 8 * lg;
+                    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+                    const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                    float rH[8], rL[8];
+                    unpack4(make_uint2(rh[mj][k].x, rh[mj][k].y), rH, p.f16);
+                    unpack4(make_uint2(rh[mj][k].z, rh[mj][k].w), rH + 4, p.f16);
+                    unpack4(make_uint2(rl[mj][k].x, rl[mj][k].y), rL, p.f16);
+                    unpack4(make_uint2(rl[mj][k].z, rl[mj][k].w), rL + 4, p.f16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[2 * k][mi][i] = ((acc[2 * k][mi][i] + b[i]) + rH[i]) + rL[i];
+                        acc[2 * k + 1][mi][i] = ((acc[2 * k + 1][mi][i] + b[4 + i]) + rH[4 + i]) + rL[4 + i];
+                    }
+                }
+            }
+        }
+        // 2. local sums over this workgroup's 192 columns
+        float ml[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            float t = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 6; ++ni) t += (acc[ni][mi][0] + acc[ni][mi][1]) + (acc[ni][mi][2] + acc[ni][mi][3]);
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (lg == 0) red[wn * 256 + wm * 64 + mi * 16 + lr] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int row = wm * 64 + mi * 16 + lr;
+            ml[mi] = (red[row] + red[256 + row]) * (1.0f / BBN);
+        }
+        // 3. local M2 about the local mean
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            float q = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 6; ++ni)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = acc[ni][mi][i] - ml[mi];
+                    q += d * d;
+                }
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (lg == 0) red2[wn * 256 + wm * 64 + mi * 16 + lr] = q;
+        }
+        __syncthreads();
+        // 4.-6. exchange with the band mates, placement-independent and fence-free: every statistic travels as an
+        // 8-byte {tag = epoch, value} granule written and polled with relaxed agent-scope atomics (write-through
+        // stores, L1-bypassing loads; cdna_hip_programming.md Guideline 16, recipe R2: the data is the flag).
+        // Thread t owns row t: it publishes this tile's (sum, M2) and sweeps the 2 x tiles_n granules of its row
+        // until every tag matches.  Stale granules carry an older epoch (the buffer is zeroed once per batch of
+        // launches, epochs count up from 1).  The sweep is bounded: a lost mate gives wrong numbers, never a hung GPU.
+        const int band = tile / p.tiles_n, tn = tile % p.tiles_n;
+        typedef __attribute__((address_space(1))) unsigned long long gu64;
+        gu64* gran = (gu64*)(p.ln_stats + (size_t)band * p.tiles_n * 512);  // [tiles_n][256 rows][2]
+        if (tid < 256) {
+            const unsigned long long ep = (unsigned long long)p.ln_epoch << 32;
+            const float S_loc = red[tid] + red[256 + tid], M2_loc = red2[tid] + red2[256 + tid];
+            __hip_atomic_store(gran + ((size_t)tn * 256 + tid) * 2, ep | __builtin_bit_cast(unsigned, S_loc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gran + ((size_t)tn * 256 + tid) * 2 + 1, ep | __builtin_bit_cast(unsigned, M2_loc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float sj[4], qj[4];
+            for (int spins = 0; spins < (1 << 20); ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sj[j] = 0.f; qj[j] = 0.f;
+                    if (j < p.tiles_n) {
+                        const unsigned long long x0 = __hip_atomic_load(gran + ((size_t)j * 256 + tid) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long x1 = __hip_atomic_load(gran + ((size_t)j * 256 + tid) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && (unsigned)(x0 >> 32) == p.ln_epoch && (unsigned)(x1 >> 32) == p.ln_epoch;
+                        sj[j] = __builtin_bit_cast(float, (unsigned)x0);
+                        qj[j] = __builtin_bit_cast(float, (unsigned)x1);
+                    }
+                }
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            // combine: mean, then M2 = sum_j [M2_j + n_j (mean_j - mean)^2]
+            const float n_all = (float)(p.tiles_n * BBN);
+            const float mean = ((sj[0] + sj[1]) + (sj[2] + sj[3])) / n_all;
+            float M2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < p.tiles_n) {
+                    const float dj = sj[j] * (1.0f / BBN) - mean;
+                    M2 += qj[j] + (float)BBN * dj * dj;
+                }
+            }
+            mr[tid] = make_float2(mean, 1.0f / sqrtf(M2 / n_all + p.ln_eps));
+        }
+        __syncthreads();
+        // 7. normalise this workgroup's slice and store it
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int n = n0 + wn * 96 + 32 * k + 8 * lg;
+            const float4 g0 = *reinterpret_cast<const float4*>(p.ln_gamma + n), g1 = *reinterpret_cast<const float4*>(p.ln_gamma + n + 4);
+            const float4 c0 = *reinterpret_cast<const float4*>(p.ln_beta + n), c1 = *reinterpret_cast<const float4*>(p.ln_beta + n + 4);
+            const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int row = wm * 64 + mi * 16 + lr;
+                const int m = m0 + row;
+                if (m >= p.M) continue;
+                const float2 s2 = mr[row];
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    y[i] = (acc[2 * k][mi][i] - s2.x) * s2.y * g[i] + c[i];
+                    y[4 + i] = (acc[2 * k + 1][mi][i] - s2.x) * s2.y * g[4 + i] + c[4 + i];
+                }
+                const size_t o = (size_t)m * p.ldc + n;
+                if (p.C_f32) {
+                    *reinterpret_cast<float4*>(p.C_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
+                    *reinterpret_cast<float4*>(p.C_f32 + o + 4) = make_float4(y[4], y[5], y[6], y[7]);
+                }
+                uint2 h0, l0, h1, l1;
+                split4(y, h0, l0, p.f16);
+                split4(y + 4, h1, l1, p.f16);
+                *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                *reinterpret_cast<uint4*>(p.C_lo + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
             }
         }
     }
@@ -814,7 +976,7 @@ static bool opt_in_lds() {
 }
 template <int NPASS, bool F16>
 static bool opt_in_lds_pp() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<NPASS, F16>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<NPASS, F16, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess;
 }
 // experiment knob: DIDI_GEMM_PP=0 selects the in-phase K-loop (gemm_big_kernel) for A/B timing
@@ -872,9 +1034,9 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
             p.tiles_m = cdiv(p.M, 256);
             const int grid = p.tiles_m * p.tiles_n;
             const size_t lds = 2 * BigGeom<4>::STAGE + 8192;  // + GELU table
-            if (mode == 3) gemm_pp_kernel<3, false><<<grid, 512, lds, st>>>(p);
-            else if (p.f16) gemm_pp_kernel<1, true><<<grid, 512, lds, st>>>(p);
-            else gemm_pp_kernel<1, false><<<grid, 512, lds, st>>>(p);
+            if (mode == 3) gemm_pp_kernel<3, false, false><<<grid, 512, lds, st>>>(p);
+            else if (p.f16) gemm_pp_kernel<1, true, false><<<grid, 512, lds, st>>>(p);
+            else gemm_pp_kernel<1, false, false><<<grid, 512, lds, st>>>(p);
             DIDI_LAUNCH_CHECK();
             return DIDI_OK;
         }
@@ -891,6 +1053,73 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
         else gemm_kernel<0, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
     }
     DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ output projection + residual + LayerNorm
+static int ln_cus() {  // workgroups that are certainly co-resident: one per CU (the kernel takes 120 KiB of LDS)
+    static const int n = [] {
+        int dev = 0, c = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 0;
+        return c;
+    }();
+    return n;
+}
+
+extern "C" int didi_gemm_ln_supported(int M, int N, int K, int precision) {
+    const bool prec_ok = precision == DIDI_PREC_BF16 || precision == DIDI_PREC_FP16 || precision == DIDI_PREC_BF16X3;
+    return prec_ok && M >= 2048 && N == 4 * BBN && K % 64 == 0 && K >= 128;
+}
+
+extern "C" size_t didi_gemm_ln_stats_bytes(int M) { return (size_t)cdiv(M, 256) * 4 * 256 * 2 * sizeof(unsigned long long); }
+
+extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, uint16_t* y_hi,
+                            uint16_t* y_lo, float* y_f32, void* stats, uint32_t epoch, void* stream) {
+    DIDI_CHECK_ARG(a && a->A_hi && a->W_hi && a->bias && gamma && beta && y_hi && y_lo && stats && a->M >= 0);
+    DIDI_CHECK_ARG(a->act == DIDI_ACT_NONE && !a->C_f32 && !a->C_hi && !a->C_lo && a->R_hi && a->R_lo && !a->R_f32);
+    if (!didi_gemm_ln_supported(a->M, a->N, a->K, a->precision)) return DIDI_ERR_UNSUPPORTED;
+    DIDI_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K && a->ldr % 8 == 0 && a->ldr >= a->N);
+    DIDI_CHECK_ARG(al16(a->A_hi) && al16(a->A_lo) && al16(a->W_hi) && al16(a->W_lo) && al16(a->bias) && al16(a->R_hi) && al16(a->R_lo));
+    DIDI_CHECK_ARG(al16(gamma) && al16(beta) && al16(y_hi) && al16(y_lo) && al16(y_f32) && al16(stats));
+    if (a->M == 0) return DIDI_OK;
+    const int ncu = ln_cus();
+    if (ncu < 4) return DIDI_ERR_LAUNCH;
+    GemmParams p{};
+    p.N = a->N; p.K = a->K;
+    int rc = fill_operands(p, a->precision, a->A_hi, a->A_lo, a->W_hi, a->W_lo);
+    if (rc != DIDI_OK) return rc;
+    if (!allow_big_lds()) return DIDI_ERR_LAUNCH;
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess &&
+                           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess &&
+                           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess;
+    if (!ok) return DIDI_ERR_LAUNCH;
+    p.lda = a->lda; p.ldw = a->ldw; p.bias = a->bias; p.act = DIDI_ACT_NONE; p.ldr = a->ldr; p.ldc = a->N;
+    p.ln_gamma = gamma; p.ln_beta = beta; p.ln_eps = eps; p.tiles_n = 4;
+    hipStream_t st = as_stream(stream);
+    const int bands = cdiv(a->M, 256);
+    if (epoch == 0) {  // stand-alone use: clear the granules, then tag 1
+        if (hipMemsetAsync(stats, 0, didi_gemm_ln_stats_bytes(a->M), st) != hipSuccess) return DIDI_ERR_LAUNCH;
+        epoch = 1;
+    }
+    p.ln_epoch = epoch;
+    // row chunks of at most (CUs / 4) bands: every workgroup of a launch is resident, so band mates never wait for a CU
+    const int bands_per_launch = ncu / 4;
+    const size_t lds = 2 * BigGeom<4>::STAGE + 8192;
+    for (int b0 = 0; b0 < bands; b0 += bands_per_launch) {
+        const int nb = std::min(bands_per_launch, bands - b0);
+        const size_t r0 = (size_t)b0 * 256;
+        p.M = (int)std::min<size_t>((size_t)nb * 256, (size_t)a->M - r0);
+        p.tiles_m = nb;
+        p.A_hi = a->A_hi + r0 * a->lda; p.A_lo = (p.npass == 3 ? a->A_lo : a->A_hi) + r0 * a->lda;
+        p.R_hi = a->R_hi + r0 * a->ldr; p.R_lo = a->R_lo + r0 * a->ldr;
+        p.C_hi = y_hi + r0 * a->N; p.C_lo = y_lo + r0 * a->N; p.C_f32 = y_f32 ? y_f32 + r0 * a->N : nullptr;
+        p.ln_stats = reinterpret_cast<unsigned long long*>(stats) + (size_t)b0 * 4 * 512;
+        const int grid = nb * 4;
+        if (p.npass == 3) gemm_pp_kernel<3, false, true><<<grid, 512, lds, st>>>(p);
+        else if (p.f16) gemm_pp_kernel<1, true, true><<<grid, 512, lds, st>>>(p);
+        else gemm_pp_kernel<1, false, true><<<grid, 512, lds, st>>>(p);
+        DIDI_LAUNCH_CHECK();
+    }
     return DIDI_OK;
 }
 

@@ -101,6 +101,27 @@ def gemm(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, precision="bf16x3", residu
     return c_hi, c_lo, c_f32
 
 
+def gemm_ln(a_hi, a_lo, w_hi, w_lo, bias, residual_planes, gamma, beta, eps, precision="fp16", f32=False, out=None):
+    """LayerNorm(A W^T + bias + residual) in one launch -> (y_hi, y_lo, y_f32).  N == 768, M >= 2048.
+    ``out`` = (y_hi, y_lo) to write into (may be the residual planes themselves, as the decoder does)."""
+    M, K = a_hi.shape
+    N = w_hi.shape[0]
+    dev = a_hi.device
+    g = _lib.GemmArgs()
+    g.M, g.N, g.K, g.precision = M, N, K, _prec(precision)
+    g.A_hi, g.A_lo, g.lda = a_hi.data_ptr(), _lib.ptr(a_lo), a_hi.stride(0)
+    g.W_hi, g.W_lo, g.ldw = w_hi.data_ptr(), _lib.ptr(w_lo), w_hi.stride(0)
+    g.bias, g.act = bias.data_ptr(), _lib.ACT_NONE
+    g.R_hi, g.R_lo, g.ldr = residual_planes[0].data_ptr(), residual_planes[1].data_ptr(), residual_planes[0].stride(0)
+    pd = plane_dtype(precision)
+    y_hi, y_lo = out if out is not None else (torch.empty((M, N), dtype=pd, device=dev), torch.empty((M, N), dtype=pd, device=dev))
+    y = torch.empty((M, N), dtype=torch.float32, device=dev) if f32 else None
+    stats = torch.empty(lib.didi_gemm_ln_stats_bytes(M), dtype=torch.uint8, device=dev)
+    _lib.check(lib.didi_gemm_ln(C.byref(g), gamma.data_ptr(), beta.data_ptr(), eps, y_hi.data_ptr(), y_lo.data_ptr(), _lib.ptr(y),
+                                stats.data_ptr(), 0, _lib.current_stream()), "gemm_ln")
+    return y_hi, y_lo, y
+
+
 def attention(q, k, v, heads, causal=False, key_mask=None, precision="bf16x3"):
     """q/k/v: (hi, lo) plane pairs shaped [B, S, heads*D] (views with a row stride are fine)."""
     B, Sq, HD = q[0].shape

@@ -156,6 +156,26 @@ typedef struct didi_gemm_args {
 } didi_gemm_args;
 int didi_gemm_bf16(const didi_gemm_args* a, void* stream);
 
+/* y = LayerNorm(A W^T + bias + residual): BertSelfOutput / BertOutput in one launch -- `dense` +
+ * dropout(eval) + `LayerNorm(hidden_states + input_tensor)` (HF:models/bert/modeling_bert.py:284-295,342-353).
+ * The GEMM keeps its 256x192 tiles; the four workgroups that share a 256-row band exchange exact per-row
+ * partial statistics through `stats` and an arrival counter, then each normalises its own 192 columns
+ * from registers: the pre-norm tensor and the separate LayerNorm pass never touch HBM.
+ * Takes a didi_gemm_args with act = NONE, residual PLANES (R_hi, R_lo), bias, and no C_* outputs; writes
+ * split planes y_hi / y_lo (format of the precision; may alias the residual planes) and, if not NULL, fp32
+ * y_f32, all [M, N] dense.  Supported (didi_gemm_ln_supported != 0): N == 768 (BertConfig hidden size: the
+ * decoder of every DiDi config), M >= 2048, K % 64 == 0, any precision; otherwise DIDI_ERR_UNSUPPORTED and the
+ * caller runs didi_gemm_bf16 + didi_layernorm.  `stats`: didi_gemm_ln_stats_bytes(M) bytes, 16-byte aligned: the
+ * statistics travel as 8-byte {tag = epoch, value} words.  On entry no word of it may carry `epoch` in its upper half:
+ * zero the buffer once (hipMemsetAsync), then pass epoch = 1, 2, 3, ... to successive calls that share it;
+ * epoch == 0 makes the call zero the buffer itself and use tag 1 (stand-alone use).
+ * A launch never holds more than one workgroup per CU (rows are processed in chunks), so the workgroups that
+ * wait for each other are always co-resident; the wait is bounded in any case. */
+int didi_gemm_ln_supported(int M, int N, int K, int precision);
+size_t didi_gemm_ln_stats_bytes(int M);
+int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, uint16_t* y_hi,
+                 uint16_t* y_lo, float* y_f32, void* stats, uint32_t epoch, void* stream);
+
 /* ids[m] = argmax_n sum_p X_p[m,:] . Wc_p[n,:]  -- the "rounding" step
  * `model.classifier(x_0)` + `logits.argmax(-1)` (src/sampling.py:64,82,32) without ever writing
  * the [M, V] logits.  First (lowest) index wins ties, as torch.argmax on CPU.  Two launches:

@@ -222,6 +222,45 @@ def test_gemm_big_tile(ops, M, N, K, precision):
     assert rel_l2(c, _gemm_ref(ar, wr, bias, "gelu", ops.join(*rp).cpu())) <= tol
 
 
+@pytest.mark.parametrize("M,K", [(2048, 768), (2100, 128), (4160, 3072), (16684, 128)])
+@pytest.mark.parametrize("precision", ALL_PREC)
+def test_gemm_ln_fused(ops, M, K, precision):
+    """didi_gemm_ln == LayerNorm(A W^T + bias + residual) (fp64 reference on the same rounded operands), ragged last
+    row band, more bands than one launch holds (16684 rows = 66 bands > 256 CUs / 4), in place over the residual."""
+    N = 768
+    a, w, bias, r = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=0.05), rnd(N, seed=33), rnd(M, N, seed=34)
+    r[:, 5] += 30.0  # an outlier feature: large mean relative to the spread, as trained BERT hidden states have
+    g, b = 1 + rnd(N, seed=35, scale=0.1), rnd(N, seed=36, scale=0.1)
+    pd, x3 = PD[precision], precision == "bf16x3"
+    a_hi, a_lo = ops.split(a.cuda(), dtype=pd)
+    w_hi, w_lo = ops.split(w.cuda(), dtype=pd)
+    rp = ops.split(r.cuda(), dtype=pd)
+    r_used = ops.join(*rp).cpu()
+    y_hi, y_lo, y = ops.gemm_ln(a_hi, a_lo, w_hi, w_lo, bias.cuda(), rp, g.cuda(), b.cuda(), 1e-12, precision=precision, f32=True)
+    ar, wr = (a, w) if x3 else (a_hi.cpu().float(), w_hi.cpu().float())
+    want = torch.nn.functional.layer_norm(_gemm_ref(ar, wr, bias, None, r_used), (N,), g.double(), b.double(), 1e-12)
+    assert rel_l2(y, want) <= 5e-6, rel_l2(y, want)  # measured 2.5e-6 (bf16x3: dropped lo*lo term), 3e-7 (one product)
+    assert (y.cpu().double() - want).abs().max().item() <= 1e-3
+    assert torch.equal(y_hi.cpu(), y.cpu().to(pd)) and rel_l2(ops.join(y_hi, y_lo), y) <= 2e-5
+    # twice in a row in place (epoch 0: the call clears the statistics buffer itself), as the decoder engine uses it
+    h_hi, h_lo = rp[0].clone(), rp[1].clone()
+    ops.gemm_ln(a_hi, a_lo, w_hi, w_lo, bias.cuda(), (h_hi, h_lo), g.cuda(), b.cuda(), 1e-12, precision=precision, out=(h_hi, h_lo))
+    assert torch.equal(h_hi, y_hi) and torch.equal(h_lo, y_lo)
+
+
+def test_gemm_ln_rejects_unsupported(ops):
+    from didi_amd._lib import DidiHipError, lib
+
+    assert lib.didi_gemm_ln_supported(16384, 768, 3072, ops.PRECISIONS["fp16"]) == 1
+    assert lib.didi_gemm_ln_supported(16384, 512, 768, ops.PRECISIONS["fp16"]) == 0  # not the BertConfig hidden size
+    assert lib.didi_gemm_ln_supported(184, 768, 768, ops.PRECISIONS["fp16"]) == 0   # small batches take GEMM + LayerNorm
+    a_hi, _ = ops.split(rnd(64, 64).cuda(), dtype=torch.float16)
+    w_hi, w_lo = ops.split(rnd(768, 64).cuda(), dtype=torch.float16)
+    rp = ops.split(rnd(64, 768).cuda(), dtype=torch.float16)
+    with pytest.raises(DidiHipError):
+        ops.gemm_ln(a_hi, None, w_hi, w_lo, torch.zeros(768).cuda(), rp, torch.ones(768).cuda(), torch.zeros(768).cuda(), 1e-12)
+
+
 def test_gemm_big_tile_identity_asymmetric(ops):
     M, K = 2304, 192
     a = torch.zeros(M, K)

@@ -265,8 +265,10 @@ def test_torch_noise_loop_equals_native_loop():
 def test_full_size_decoder_properties():
     """cfg2-sized model (H=768, 12 layers, 12 heads, FFN 3072; enc 1280/32 heads/5120), S=C=64.
     (a) a B=2 slice agrees with the CPU oracle; (b) dialogs are independent: the same dialogs give
-    bit-identical output inside batches of 40 and 36 (both on the 256x192 GEMM tile) and the same
-    output to fp32 rounding in a batch of 2 (128x128 tile): batch-split invariance."""
+    bit-identical output inside batches of 40 and 36 (both on the 256x192 GEMM tile with the fused
+    projection+LayerNorm) and the same output to the split-plane rounding floor in a batch of 2 (128x128 tile,
+    GEMM then LayerNorm: the statistics are summed in another order, which moves a few lo-plane roundings of
+    2^-17 relative; measured 1.5e-5 after 12 layers): batch-split invariance."""
     from didi_amd.config import DiDiConfig
     from didi_amd.synthetic import synthetic_batch, synthetic_state_dict
     from oracle.model import OracleDiDi
@@ -281,7 +283,7 @@ def test_full_size_decoder_properties():
     out, ctx = model(encoder_input_ids=ids.cuda(), encoder_attention_mask=mask.cuda(), decoder_inputs_embeds=x_t.cuda(), time_ids=tids.cuda())
     out2, ctx2 = model(encoder_input_ids=ids[:2].cuda(), encoder_attention_mask=mask[:2].cuda(),
                        decoder_inputs_embeds=x_t[:2].cuda(), time_ids=tids[:2].cuda())
-    assert rel_l2(out[:2], out2) <= 1e-6 and rel_l2(ctx[:2], ctx2) <= 1e-6
+    assert rel_l2(out[:2], out2) <= 5e-5 and rel_l2(ctx[:2], ctx2) <= 1e-6
     out36, ctx36 = model(encoder_input_ids=ids[:36].cuda(), encoder_attention_mask=mask[:36].cuda(),
                          decoder_inputs_embeds=x_t[:36].cuda(), time_ids=tids[:36].cuda())
     assert torch.equal(out[:36], out36) and torch.equal(ctx[:36], ctx36)

@@ -60,6 +60,33 @@ def main():
             mult = 3 if prec == "bf16x3" else 1
             total[prec] += us * (2 if name.startswith('attn_out') else 1)
             print(f"{name:18s} N={N:5d} K={K:5d} {prec:7s} {us:8.1f} us  alg {fl / us / 1e6:7.1f} TF  exec {mult * fl / us / 1e6:7.1f} TF")
+    # output projection + residual + LayerNorm: fused launch vs GEMM + LayerNorm
+    if H == 768:
+        gam, bet = torch.ones(H, device="cuda"), torch.zeros(H, device="cuda")
+        for prec in ("fp16", "bf16x3"):
+            pd = ops.plane_dtype(prec)
+            for K in (H, I):
+                a_hi, a_lo = ops.split(rnd(M, K), dtype=pd)
+                w_hi, w_lo = ops.split(rnd(H, K) * 0.02, dtype=pd)
+                r = ops.split(rnd(M, H), dtype=pd)
+                bias = rnd(H)
+
+                def unfused():
+                    _, _, t = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias, precision=prec, residual_planes=r, out_f32=True, out_planes=False)
+                    ops.layernorm(t, gam, bet, 1e-12, dtype=pd)
+
+                for name, call in (("gemm_ln fused", lambda: ops.gemm_ln(a_hi, a_lo, w_hi, w_lo, bias, r, gam, bet, 1e-12, precision=prec)),
+                                   ("gemm + layernorm", unfused)):
+                    for _ in range(3):
+                        call()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(args.iters):
+                        call()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    print(f"{name:18s} N={H:5d} K={K:5d} {prec:7s} {e0.elapsed_time(e1) * 1e3 / args.iters:8.1f} us")
     layer_fl = 2.0 * M * (3 * H * H + 3 * H * H + 2 * H * I)
     for prec, us in total.items():
         print(f"sum of 6 GEMMs per layer ({prec}): {us + 0:8.1f} us (cross_out counted as attn_out) -> alg {layer_fl / (us) / 1e6:7.1f} TF")

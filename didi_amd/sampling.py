@@ -25,6 +25,8 @@ Extra keyword-only arguments (all optional; defaults reproduce the reference cal
   trace   list      receives the denoiser input x_t of every call (fp32 [B,S,H], on device)
   return_ids        return (ids [B,S] int64, lengths [B] int32) instead of decoded strings
   philox_offset     first Philox counter of this call (didi_amd/dist.py gives every rank a disjoint range)
+  target_len        reply length S, overriding ``len(range(C)[:max_len])``: lets a batch whose context padding was trimmed
+                    (didi_amd/hostio.py) keep the reply length of the untrimmed batch
   clamp             per-step clamp extension of BASELINE config 4 (NOT in the reference): after every denoiser
                     call x0 <- emb[argmax(classifier(x0))] before the sampler update
 """
@@ -58,14 +60,14 @@ def _host_arrays(plan, mode):
 
 @torch.no_grad()
 def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, max_len=-1, raw_output=False,
-           skip_special=True, *, noise=None, trace=None, return_ids=False, philox_offset=0, clamp=False, _prof=None):
+           skip_special=True, *, noise=None, trace=None, return_ids=False, philox_offset=0, clamp=False, target_len=None, _prof=None):
     if mode not in ("ddpm", "euler"):
         raise NotImplementedError(f"No {mode} sampling strategy")
     if not raw_output and not return_ids and tokenizer is None:
         raise ValueError("`tokenizer` must be provided.")
     input_ids, attention_mask = raw_context.input_ids, raw_context.attention_mask
     B, Cn = input_ids.shape
-    S = _target_len(Cn, max_len)
+    S = _target_len(Cn, max_len) if target_len is None else int(target_len)
     H, V = model.cfg.dec_dim, model.cfg.vocab
     dev = model.device
     if S < 1:

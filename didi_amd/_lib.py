@@ -123,6 +123,9 @@ SYMBOLS = [
     ("didi_gemm_ln", C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_uint32, C.c_void_p]),
     ("didi_round_argmax_bytes", C.c_size_t, [C.c_int, C.c_int]),
+    ("didi_round_ce_bytes", C.c_size_t, [C.c_int, C.c_int]),
+    ("didi_round_ce", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("didi_round_argmax", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("didi_first_eos", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),

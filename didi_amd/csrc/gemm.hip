@@ -9,7 +9,8 @@
 //   gemm_big_kernel  same tile, in-phase K-loop (A/B baseline, DIDI_GEMM_PP=0; MT=2: 128 x 192, 4 waves)
 //   gemm_kernel      128 x 128 tile, 4 waves (2 x 2 of 64 x 64)                   small M, odd N
 //   tile_regstage    register-staged fallback inside gemm_kernel                  K not a multiple of the K-tile
-//   gemm_argmax_kernel  128-row tiles over vocabulary chunks, running (max, index), logits never written
+//   gemm_argmax_kernel  128-row tiles over vocabulary chunks, running (max, index), logits never written;
+//                       CE variant: also an online log-sum-exp and the target's logit (validation cross-entropy)
 // The MFMA is issued "swapped" (A-operand = weight rows, B-operand = activation rows) so that every
 // lane ends up holding CONSECUTIVE OUTPUT COLUMNS n of one output row m: the epilogue then loads
 // bias as float4s and stores 8/16-byte plane packs and 16-byte fp32 vectors instead of scalars.
@@ -62,6 +63,8 @@ struct GemmParams {
     // argmax variant
     int tiles_m, tiles_n, nchunks, tiles_per_chunk;
     float2* partial;  // [M][nchunks] (value, index bits)
+    float2* partial2;          // CE variant: [M][nchunks] (sum exp(logit - chunk max), target logit or -inf)
+    const int64_t* targets;    // CE variant: [M] target ids
     // fused LayerNorm epilogue (gemm_pp_kernel<.., LN = true>): y = LayerNorm(acc + bias + residual) -> C_*
     const float *ln_gamma, *ln_beta;
     float ln_eps;
@@ -1128,7 +1131,7 @@ extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const f
 // (max, index) and never writes logits.  Cross-lane / cross-wave reduction once per workgroup.
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
-template <int MODE, int NSTAGE, bool F16>
+template <int MODE, int NSTAGE, bool F16, bool CE = false>
 __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_argmax_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int mt = blockIdx.x % p.tiles_m, chunk = blockIdx.x / p.tiles_m;
@@ -1139,6 +1142,21 @@ __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_argmax_kernel(G
     int bidx[4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) { best[mi] = -INFINITY; bidx[mi] = 0x7fffffff; }
+    // CE variant: online log-sum-exp (running max rmax, sum of exp(v - rmax)) and the target's logit
+    constexpr float LOG2E = 1.4426950408889634f;
+    float rmax[4], rsum[4], tgt[4];
+    int tg[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        rmax[mi] = -INFINITY; rsum[mi] = 0.f; tgt[mi] = -INFINITY; tg[mi] = -1;
+        if constexpr (CE) {
+            const int m = m0 + wm * 64 + mi * 16 + lr;
+            if (m < p.M) {
+                const int64_t t = p.targets[m];
+                tg[mi] = (t >= 0 && t < p.N) ? (int)t : -1;
+            }
+        }
+    }
     const int t_begin = chunk * p.tiles_per_chunk;
     const int t_end = min(t_begin + p.tiles_per_chunk, p.tiles_n);
     for (int tn = t_begin; tn < t_end; ++tn) {
@@ -1155,7 +1173,39 @@ __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_argmax_kernel(G
                     const float v = acc[ni][mi][r];
                     if (n < p.N && better(v, n, best[mi], bidx[mi])) { best[mi] = v; bidx[mi] = n; }
                 }
+        if constexpr (CE) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + wn * 64 + ni * 16 + lg * 4 + r < p.N) tmax = fmaxf(tmax, acc[ni][mi][r]);
+                if (tmax > -INFINITY) {
+                    const float nm = fmaxf(rmax[mi], tmax);
+                    float sacc = rsum[mi] * __builtin_amdgcn_exp2f((rmax[mi] - nm) * LOG2E);  // rmax = -inf: 0 * 0
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = n0 + wn * 64 + ni * 16 + lg * 4 + r;
+                            if (n < p.N) {
+                                sacc += __builtin_amdgcn_exp2f((acc[ni][mi][r] - nm) * LOG2E);
+                                if (n == tg[mi]) tgt[mi] = acc[ni][mi][r];
+                            }
+                        }
+                    rsum[mi] = sacc; rmax[mi] = nm;
+                }
+            }
+        }
     }
+    auto lse_merge = [&](float& m1, float& s1, float m2, float s2) {
+        const float nm = fmaxf(m1, m2);
+        if (nm == -INFINITY) { s1 = 0.f; return; }
+        s1 = s1 * __builtin_amdgcn_exp2f((m1 - nm) * LOG2E) + s2 * __builtin_amdgcn_exp2f((m2 - nm) * LOG2E);
+        m1 = nm;
+    };
     // lanes lr, lr+16, lr+32, lr+48 hold the same rows
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -1164,14 +1214,24 @@ __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_argmax_kernel(G
             const float ov = __shfl_xor(best[mi], o, 64);
             const int oi = __shfl_xor(bidx[mi], o, 64);
             if (better(ov, oi, best[mi], bidx[mi])) { best[mi] = ov; bidx[mi] = oi; }
+            if constexpr (CE) {
+                const float om = __shfl_xor(rmax[mi], o, 64), os = __shfl_xor(rsum[mi], o, 64), ot = __shfl_xor(tgt[mi], o, 64);
+                lse_merge(rmax[mi], rsum[mi], om, os);
+                tgt[mi] = fmaxf(tgt[mi], ot);
+            }
         }
     }
     __syncthreads();  // all waves are done with the staging buffers
     float* rv = reinterpret_cast<float*>(smem);       // [128]
     int* ri = reinterpret_cast<int*>(smem + 512);      // [128]
+    float* rm = reinterpret_cast<float*>(smem + 1024), *rs = rm + 128, *rt = rs + 128;  // CE: [128] each
     if (wn == 1 && lg == 0) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) { rv[wm * 64 + mi * 16 + lr] = best[mi]; ri[wm * 64 + mi * 16 + lr] = bidx[mi]; }
+        for (int mi = 0; mi < 4; ++mi) {
+            const int ml = wm * 64 + mi * 16 + lr;
+            rv[ml] = best[mi]; ri[ml] = bidx[mi];
+            if constexpr (CE) { rm[ml] = rmax[mi]; rs[ml] = rsum[mi]; rt[ml] = tgt[mi]; }
+        }
     }
     __syncthreads();
     if (wn == 0 && lg == 0) {
@@ -1183,6 +1243,11 @@ __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_argmax_kernel(G
                 float v = best[mi]; int i = bidx[mi];
                 if (better(rv[ml], ri[ml], v, i)) { v = rv[ml]; i = ri[ml]; }
                 p.partial[(size_t)m * p.nchunks + chunk] = make_float2(v, __int_as_float(i));
+                if constexpr (CE) {  // the chunk max is v: the sum is relative to it
+                    float cm = rmax[mi], cs = rsum[mi];
+                    lse_merge(cm, cs, rm[ml], rs[ml]);
+                    p.partial2[(size_t)m * p.nchunks + chunk] = make_float2(cs, fmaxf(tgt[mi], rt[ml]));
+                }
             }
         }
     }
@@ -1202,15 +1267,59 @@ __global__ void __launch_bounds__(256) argmax_reduce_kernel(const float2* partia
     if (ids32) ids32[m] = bi;
 }
 
+// CE variant: ids as above, nll[m] = logsumexp(logits[m, :]) - logits[m, target[m]] (+inf for a target outside [0, V))
+__global__ void __launch_bounds__(256) ce_reduce_kernel(const float2* partial, const float2* partial2, int M, int nchunks, int V,
+                                                        int64_t* ids64, float* nll) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int c = 0; c < nchunks; ++c) {
+        const float2 q = partial[(size_t)m * nchunks + c];
+        const int i = __float_as_int(q.y);
+        if (better(q.x, i, bv, bi)) { bv = q.x; bi = i; }
+    }
+    float ssum = 0.f, t = -INFINITY;
+    for (int c = 0; c < nchunks; ++c) {
+        const float2 q = partial[(size_t)m * nchunks + c];
+        const float2 r = partial2[(size_t)m * nchunks + c];
+        ssum += r.x * expf(q.x - bv);
+        t = fmaxf(t, r.y);
+    }
+    if (bi < 0 || bi >= V) bi = 0;
+    if (ids64) ids64[m] = bi;
+    nll[m] = (bv + logf(ssum)) - t;
+}
+
 extern "C" size_t didi_round_argmax_bytes(int M, int V) {
     if (M <= 0 || V <= 0) return 0;
     return (size_t)M * (size_t)cdiv(V, BN) * sizeof(float2);
 }
 
+extern "C" size_t didi_round_ce_bytes(int M, int V) { return 2 * didi_round_argmax_bytes(M, V); }
+
+static int round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uint16_t* W_hi, const uint16_t* W_lo, int ldw,
+                      int M, int V, int K, int precision, void* partial, int64_t* ids64, int32_t* ids32, const int64_t* targets,
+                      float* nll, void* stream);
+
 extern "C" int didi_round_argmax(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uint16_t* W_hi,
                                  const uint16_t* W_lo, int ldw, int M, int V, int K, int precision, void* partial,
                                  int64_t* ids64, int32_t* ids32, void* stream) {
-    DIDI_CHECK_ARG(X_hi && W_hi && partial && (ids64 || ids32) && M >= 0 && V > 0 && K > 0);
+    DIDI_CHECK_ARG(ids64 || ids32);
+    return round_impl(X_hi, X_lo, ldx, W_hi, W_lo, ldw, M, V, K, precision, partial, ids64, ids32, nullptr, nullptr, stream);
+}
+
+extern "C" int didi_round_ce(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uint16_t* W_hi, const uint16_t* W_lo,
+                             int ldw, int M, int V, int K, int precision, const int64_t* targets, void* partial, int64_t* ids64,
+                             float* nll, void* stream) {
+    DIDI_CHECK_ARG(targets && nll);
+    return round_impl(X_hi, X_lo, ldx, W_hi, W_lo, ldw, M, V, K, precision, partial, ids64, nullptr, targets, nll, stream);
+}
+
+static int round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uint16_t* W_hi, const uint16_t* W_lo, int ldw,
+                      int M, int V, int K, int precision, void* partial, int64_t* ids64, int32_t* ids32, const int64_t* targets,
+                      float* nll, void* stream) {
+    const bool ce = targets != nullptr;
+    DIDI_CHECK_ARG(X_hi && W_hi && partial && M >= 0 && V > 0 && K > 0);
     if (K % 8 != 0) return DIDI_ERR_UNSUPPORTED;
     DIDI_CHECK_ARG(ldx % 8 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K);
     DIDI_CHECK_ARG(al16(X_hi) && al16(X_lo) && al16(W_hi) && al16(W_lo) && al8(partial));
@@ -1227,21 +1336,27 @@ extern "C" int didi_round_argmax(const uint16_t* X_hi, const uint16_t* X_lo, int
     p.tiles_per_chunk = cdiv(p.tiles_n, nchunks);
     p.nchunks = cdiv(p.tiles_n, p.tiles_per_chunk);
     p.partial = reinterpret_cast<float2*>(partial);
+    p.partial2 = p.partial + (size_t)M * cdiv(V, BN);  // second half of didi_round_ce_bytes
+    p.targets = targets;
     hipStream_t st = as_stream(stream);
     const int grid = p.tiles_m * p.nchunks;
-    switch (pick_mode(p)) {
-        case 3: gemm_argmax_kernel<3, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p); break;
-        case 1:
-            if (p.f16) gemm_argmax_kernel<1, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
-            else gemm_argmax_kernel<1, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
-            break;
-        default:
-            if (p.f16) gemm_argmax_kernel<0, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
-            else gemm_argmax_kernel<0, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
-            break;
+#define DIDI_ROUND_LAUNCH(CE_)                                                                           \
+    switch (pick_mode(p)) {                                                                              \
+        case 3: gemm_argmax_kernel<3, 2, false, CE_><<<grid, 256, SMEM_BYTES, st>>>(p); break;           \
+        case 1:                                                                                          \
+            if (p.f16) gemm_argmax_kernel<1, 2, true, CE_><<<grid, 256, SMEM_BYTES, st>>>(p);            \
+            else gemm_argmax_kernel<1, 2, false, CE_><<<grid, 256, SMEM_BYTES, st>>>(p);                 \
+            break;                                                                                       \
+        default:                                                                                         \
+            if (p.f16) gemm_argmax_kernel<0, 2, true, CE_><<<grid, 256, SMEM_BYTES, st>>>(p);            \
+            else gemm_argmax_kernel<0, 2, false, CE_><<<grid, 256, SMEM_BYTES, st>>>(p);                 \
+            break;                                                                                       \
     }
+    if (ce) { DIDI_ROUND_LAUNCH(true) } else { DIDI_ROUND_LAUNCH(false) }
+#undef DIDI_ROUND_LAUNCH
     DIDI_LAUNCH_CHECK();
-    argmax_reduce_kernel<<<cdiv(M, 256), 256, 0, st>>>(p.partial, M, p.nchunks, V, ids64, ids32);
+    if (ce) ce_reduce_kernel<<<cdiv(M, 256), 256, 0, st>>>(p.partial, p.partial2, M, p.nchunks, V, ids64, nll);
+    else argmax_reduce_kernel<<<cdiv(M, 256), 256, 0, st>>>(p.partial, M, p.nchunks, V, ids64, ids32);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

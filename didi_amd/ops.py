@@ -153,6 +153,21 @@ def round_argmax(x_hi, x_lo, w_hi, w_lo, precision="bf16x3"):
     return ids
 
 
+def round_ce(x_hi, x_lo, w_hi, w_lo, targets, precision="bf16x3"):
+    """-> (ids [M] int64, nll [M] fp32): argmax and per-token cross-entropy terms of X W^T, logits never written."""
+    M, K = x_hi.shape
+    V = w_hi.shape[0]
+    targets = targets.reshape(-1).to(device=x_hi.device, dtype=torch.int64).contiguous()
+    assert targets.numel() == M
+    partial = torch.empty(lib.didi_round_ce_bytes(M, V), dtype=torch.uint8, device=x_hi.device)
+    ids = torch.empty(M, dtype=torch.int64, device=x_hi.device)
+    nll = torch.empty(M, dtype=torch.float32, device=x_hi.device)
+    _lib.check(lib.didi_round_ce(x_hi.data_ptr(), _lib.ptr(x_lo), x_hi.stride(0), w_hi.data_ptr(), _lib.ptr(w_lo), w_hi.stride(0),
+                                 M, V, K, _prec(precision), targets.data_ptr(), partial.data_ptr(), ids.data_ptr(), nll.data_ptr(),
+                                 _lib.current_stream()), "round_ce")
+    return ids, nll
+
+
 def first_eos(ids, eos_id):
     B, S = ids.shape
     assert ids.dtype == torch.int64 and ids.is_contiguous()

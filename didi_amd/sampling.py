@@ -25,6 +25,8 @@ Extra keyword-only arguments (all optional; defaults reproduce the reference cal
   trace   list      receives the denoiser input x_t of every call (fp32 [B,S,H], on device)
   return_ids        return (ids [B,S] int64, lengths [B] int32) instead of decoded strings
   philox_offset     first Philox counter of this call (didi_amd/dist.py gives every rank a disjoint range)
+  return_x0         return the denoised embeddings x0 [B, S, H] fp32 (what ``classifier`` is applied to, :64,:82) instead of
+                    logits / strings: didi_amd/validation.py rounds them with a cross-entropy epilogue
   target_len        reply length S, overriding ``len(range(C)[:max_len])``: lets a batch whose context padding was trimmed
                     (didi_amd/hostio.py) keep the reply length of the untrimmed batch
   clamp             per-step clamp extension of BASELINE config 4 (NOT in the reference): after every denoiser
@@ -60,10 +62,10 @@ def _host_arrays(plan, mode):
 
 @torch.no_grad()
 def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, max_len=-1, raw_output=False,
-           skip_special=True, *, noise=None, trace=None, return_ids=False, philox_offset=0, clamp=False, target_len=None, _prof=None):
+           skip_special=True, *, noise=None, trace=None, return_ids=False, philox_offset=0, clamp=False, target_len=None, return_x0=False, _prof=None):
     if mode not in ("ddpm", "euler"):
         raise NotImplementedError(f"No {mode} sampling strategy")
-    if not raw_output and not return_ids and tokenizer is None:
+    if not raw_output and not return_ids and not return_x0 and tokenizer is None:
         raise ValueError("`tokenizer` must be provided.")
     input_ids, attention_mask = raw_context.input_ids, raw_context.attention_mask
     B, Cn = input_ids.shape
@@ -100,7 +102,7 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
         if tuple(noise_t.shape) != (n_draws, B, S, H):
             raise ValueError(f"injected noise must have shape {(n_draws, B, S, H)}, got {tuple(noise_t.shape)}")
 
-    want_ids = not raw_output
+    want_ids = not raw_output and not return_x0
     if isinstance(noise, str):
         _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp)
         if want_ids:
@@ -134,6 +136,8 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
         if trace is not None:
             trace.extend(xt_trace.unbind(0))
 
+    if return_x0:
+        return b["x0"].view(B, S, H).clone()
     if raw_output:
         return model.classifier(b["x0"])  # [B, S, V] fp32 logits (sampling.py:64,82)
 

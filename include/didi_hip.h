@@ -187,6 +187,17 @@ int didi_round_argmax(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const
                       const uint16_t* W_lo, int ldw, int M, int V, int K, int precision, void* partial,
                       int64_t* ids64, int32_t* ids32, void* stream);
 
+/* The same GEMM with a cross-entropy epilogue: what `DiDi.validation_step` (src/diffusion/model.py:248-254) computes
+ * from `sample(..., raw_output=True)` -- `logits.argmax(-1)` and the per-token terms of `calculate_batch_ce`
+ * (src/metrics.py:91-93) -- without writing the [M, V] logits:
+ *   ids64[m] = argmax_n logits[m, n]         (may be NULL)
+ *   nll[m]   = logsumexp_n logits[m, n] - logits[m, targets[m]]      (+inf when targets[m] is outside [0, V))
+ * The caller applies the non-pad mask and the means.  `partial`: didi_round_ce_bytes(M, V) bytes. */
+size_t didi_round_ce_bytes(int M, int V);
+int didi_round_ce(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uint16_t* W_hi, const uint16_t* W_lo,
+                  int ldw, int M, int V, int K, int precision, const int64_t* targets, void* partial, int64_t* ids64,
+                  float* nll, void* stream);
+
 /* lengths[b] = (index of first eos in ids[b, :]) + 1, or S when the row holds none:
  * `truncate_predictions` (src/sampling.py:104-113) without its per-row D2H sync. */
 int didi_first_eos(const int64_t* ids, int B, int S, int64_t eos_id, int32_t* lengths, void* stream);

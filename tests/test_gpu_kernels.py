@@ -327,6 +327,30 @@ def test_round_argmax_first_index_wins_ties(ops):
         assert (ids == 3).all(), ids
 
 
+@pytest.mark.parametrize("M,V,K", [(184, 8008, 128), (300, 8008, 768), (5, 130, 64), (1, 100, 64), (168, 50000, 768)])
+@pytest.mark.parametrize("precision", ALL_PREC)
+def test_round_ce(ops, M, V, K, precision):
+    """didi_round_ce: argmax + per-token cross-entropy terms (logsumexp - target logit) of X W^T against fp64 logits of the
+    same rounded operands (what F.cross_entropy(reduction='none') gives); a target outside [0, V) yields +inf."""
+    x, w = rnd(M, K, seed=21, scale=3.0), rnd(V, K, seed=22, scale=0.05)
+    tg = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(23))
+    x_hi, x_lo = ops.split(x.cuda(), dtype=PD[precision])
+    w_hi, w_lo = ops.split(w.cuda(), dtype=PD[precision])
+    ids, nll = ops.round_ce(x_hi, x_lo, w_hi, w_lo, tg.cuda(), precision)
+    if precision != "bf16x3":
+        logits = x_hi.cpu().double() @ w_hi.cpu().double().t()
+    else:
+        logits = x.double() @ w.double().t()
+    want = torch.nn.functional.cross_entropy(logits, tg, reduction="none")
+    tol = 2e-4 if precision == "bf16x3" else 2e-5  # bf16x3 drops the lo*lo product: logits to ~1e-5 of |x||w|
+    assert (nll.cpu().double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item()), (nll.cpu().double() - want).abs().max()
+    assert torch.equal(ids.cpu(), ops.round_argmax(x_hi, x_lo, w_hi, w_lo, precision).cpu())
+    bad = tg.clone()
+    bad[0] = V
+    _, nll2 = ops.round_ce(x_hi, x_lo, w_hi, w_lo, bad.cuda(), precision)
+    assert torch.isinf(nll2[0]).item() and nll2[0].item() > 0 and torch.equal(nll2[1:], nll[1:])
+
+
 def test_first_eos(ops):
     ids = torch.randint(5, 100, (9, 23), generator=torch.Generator().manual_seed(1))
     ids[0, 0] = 2

@@ -243,6 +243,38 @@ def test_lightning_checkpoint_loader(tmp_path):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("name", ["tiny_ddpm_f1", "tiny_euler_f2"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16"])
+def test_validation_step_against_reference_logits(name, precision):
+    """DiDi.validation_step (model.py:245-254): CE over non-pad target tokens and token accuracy.  Expected values are
+    computed from the REFERENCE run's logits in the fixture (calculate_batch_ce, metrics.py:91-93); ours come from the
+    classifier GEMM's cross-entropy epilogue (no logits in memory)."""
+    from didi_amd.synthetic import RawContext
+    from didi_amd.validation import validation_step
+
+    t, meta = load_case(name)
+    run = meta["run"]
+    model = _model(weights_of(load_case("tiny_weights")[0]), spec_to_config(meta["spec"]), precision)
+    noise = torch.stack(noise_list(t, int(meta["n_noise"])))
+    logits = t["out.logits"]
+    B, S, V = logits.shape
+    g = torch.Generator().manual_seed(77)
+    tgt = torch.where(torch.rand(B, S, generator=g) < 0.5, logits.argmax(-1), torch.randint(0, V, (B, S), generator=g))
+    lens = torch.randint(1, S + 1, (B,), generator=g)
+    tmask = (torch.arange(S)[None, :] < lens[:, None]).long()
+    keep = tmask.bool().view(-1)
+    want_ce = torch.nn.functional.cross_entropy(logits.view(-1, V)[keep], tgt.view(-1)[keep]).item()
+    want_acc = (((logits.argmax(-1) == tgt) * tmask).sum() / tmask.sum()).item()
+    ce, acc = validation_step(model, _ctx(t["in.input_ids"], t["in.attention_mask"]), RawContext(tgt, tmask), run["mode"],
+                              run["step_freq"], noise=noise)
+    print(f"\n[{name} {precision}] ce {ce:.6f} (reference {want_ce:.6f})  acc {acc:.4f} (reference {want_acc:.4f})")
+    assert abs(ce - want_ce) <= (1e-4 if precision == "bf16x3" else 2e-3) * max(1.0, abs(want_ce))
+    assert abs(acc - want_acc) <= 1.0 / tmask.sum().item() + 1e-6  # at most one near-tie position
+    with pytest.raises(ValueError):  # a target longer than the sampled length cannot be compared
+        validation_step(model, _ctx(t["in.input_ids"], t["in.attention_mask"]),
+                        RawContext(torch.zeros(B, 40, dtype=torch.long), torch.ones(B, 40, dtype=torch.long)), run["mode"], run["step_freq"])
+
+
 def test_torch_noise_loop_equals_native_loop():
     """The per-call Python loop and the native didi_sample loop run the same kernels: with the same
     injected draws they must agree bit-for-bit."""

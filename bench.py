@@ -170,12 +170,19 @@ def main():
             traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
             traffic_src = os.path.relpath(tpath, ROOT)
         roofline = {
-            "bound": "mfma", "kernel": f"gemm_pp_kernel<{3 if args.precision == 'bf16x3' else 1},{'true' if args.precision == 'fp16' else 'false'}> (256x192 tile, staggered wave groups)",
+            "bound": "mfma", "kernel": (f"gemm_pp_kernel<{3 if args.precision == 'bf16x3' else 1}, {'true' if args.precision == 'fp16' else 'false'}, LN> "
+                                         "(256x192 tile, staggered wave groups; LN=true on the three output projections per layer, "
+                                         "which carry bias + residual + LayerNorm in the epilogue)"),
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches": len(dur), "avg_launch_us": round(1e3 * sum(dur) / len(dur), 2),
             "avg_gflop_per_launch": round(sum(flops) / len(flops) / 1e9, 2),
             "gemm_share_of_call": round(sum(dur) / (1e3 * elapsed / (args.steps * n_calls)), 3),
+            # launches 1, 3, 5 of every layer (attention/cross/FFN output projections) also do bias + residual + LayerNorm
+            "by_variant_tflops": {
+                "plain (qkv, cross_q, ffn_up)": round(sum(flops[0::2]) / (sum(dur[0::2]) * 1e-3) / 1e12, 1),
+                "with LayerNorm epilogue (attn_out, cross_out, ffn_down)": round(sum(flops[1::2]) / (sum(dur[1::2]) * 1e-3) / 1e12, 1),
+            },
             "note": ("algorithmic FLOPs 2*M*N*K per launch; bf16x3 issues 3 MFMA passes per product, "
                      "which are not counted" if args.precision == "bf16x3" else "algorithmic FLOPs 2*M*N*K per launch"),
         }

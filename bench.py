@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="dialogs per GPU")
     ap.add_argument("--seq", type=int, default=64, help="context length = target length")
     ap.add_argument("--diffusion-steps", type=int, default=2000)
+    ap.add_argument("--vocab", type=int, default=None, help="vocabulary size (BASELINE config 4: 50000)")
+    ap.add_argument("--clamp", action="store_true", help="config 4's per-step clamp x0 <- emb[argmax(classifier(x0))] (not in the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -125,7 +127,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dev = torch.device("cuda", local_rank)
 
-    cfg = DiDiConfig(diffusion_steps=args.diffusion_steps)
+    cfg = DiDiConfig(diffusion_steps=args.diffusion_steps, **({"vocab": args.vocab} if args.vocab else {}))
     sd = synthetic_state_dict(cfg, seed=1234)
     model = DiDiSampler(sd, cfg, device=dev, precision=args.precision)
     B_total, S = args.batch * world, args.seq
@@ -134,7 +136,7 @@ def main():
     n_calls = ddpm_plan(model._sigmas_host, cfg.diffusion_steps, args.freq).n_calls  # same count for euler
 
     def step(prof=None):
-        return ddist.sample_sharded(ctx, model, args.mode, args.freq, rank=rank, world=world, max_len=S, eos_id=2, _prof=prof)
+        return ddist.sample_sharded(ctx, model, args.mode, args.freq, rank=rank, world=world, max_len=S, eos_id=2, clamp=args.clamp, _prof=prof)
 
     def sync():
         if world > 1:
@@ -196,7 +198,8 @@ def main():
         "config": {
             "workload": (f"BASELINE configs[1]: blenderbot-400M-distill-sized encoder (2x1280/32h/5120) + BertConfig-default "
                          f"decoder (12x768/12h/3072), V={cfg.vocab}, {args.mode} T={cfg.diffusion_steps} step_freq={args.freq} "
-                         f"({n_calls} denoiser calls), batch {args.batch}/GPU, context {args.seq}, target {S}"),
+                         f"({n_calls} denoiser calls), batch {args.batch}/GPU, context {args.seq}, target {S}"
+                         + (", per-step clamp extension ON" if args.clamp else "")),
             "global_batch": B_total, "seq_len": S, "denoiser_calls": n_calls, "parallelism": f"dp{world} (batch shard, id all-gather)",
             "weights": "random-init N(0,0.02), seed 1234", "noise": "in-kernel Philox",
         },

@@ -864,7 +864,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         // stores, L1-bypassing loads; cdna_hip_programming.md Guideline 16, recipe R2: the data is the flag).
         // Thread t owns row t: it publishes this tile's (sum, M2) and sweeps the 2 x tiles_n granules of its row
         // until every tag matches.  Stale granules carry an older epoch (the buffer is zeroed once per batch of
-        // launches, epochs count up from 1).  The sweep is bounded: a lost mate gives wrong numbers, never a hung GPU.
+        // launches, epochs count up from 1).  The sweep is bounded: a lost mate gives NaN rows, never a hung GPU.
         const int band = tile / p.tiles_n, tn = tile % p.tiles_n;
         typedef __attribute__((address_space(1))) unsigned long long gu64;
         gu64* gran = (gu64*)(p.ln_stats + (size_t)band * p.tiles_n * 512);  // [tiles_n][256 rows][2]
@@ -874,6 +874,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
             __hip_atomic_store(gran + ((size_t)tn * 256 + tid) * 2, ep | __builtin_bit_cast(unsigned, S_loc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(gran + ((size_t)tn * 256 + tid) * 2 + 1, ep | __builtin_bit_cast(unsigned, M2_loc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             float sj[4], qj[4];
+            bool complete = false;
             for (int spins = 0; spins < (1 << 20); ++spins) {
                 bool ok = true;
 #pragma unroll
@@ -887,7 +888,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                         qj[j] = __builtin_bit_cast(float, (unsigned)x1);
                     }
                 }
-                if (__all(ok)) break;
+                if (__all(ok)) { complete = true; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             // combine: mean, then M2 = sum_j [M2_j + n_j (mean_j - mean)^2]
@@ -901,7 +902,9 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                     M2 += qj[j] + (float)BBN * dj * dj;
                 }
             }
-            mr[tid] = make_float2(mean, 1.0f / sqrtf(M2 / n_all + p.ln_eps));
+            // a sweep that gave up (a band mate never ran: the launch was not co-resident) poisons its rows, so the failure
+            // shows as NaN downstream instead of as plausible numbers
+            mr[tid] = complete ? make_float2(mean, 1.0f / sqrtf(M2 / n_all + p.ln_eps)) : make_float2(__builtin_nanf(""), __builtin_nanf(""));
         }
         __syncthreads();
         // 7. normalise this workgroup's slice and store it

@@ -170,7 +170,8 @@ int didi_gemm_bf16(const didi_gemm_args* a, void* stream);
  * zero the buffer once (hipMemsetAsync), then pass epoch = 1, 2, 3, ... to successive calls that share it;
  * epoch == 0 makes the call zero the buffer itself and use tag 1 (stand-alone use).
  * A launch never holds more than one workgroup per CU (rows are processed in chunks), so the workgroups that
- * wait for each other are always co-resident; the wait is bounded in any case. */
+ * wait for each other are always co-resident; the wait is bounded in any case, and rows whose wait ran out come back
+ * as NaN. */
 int didi_gemm_ln_supported(int M, int N, int K, int precision);
 size_t didi_gemm_ln_stats_bytes(int M);
 int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, uint16_t* y_hi,

@@ -20,7 +20,7 @@ i64p = C.POINTER(C.c_int64)
 OK = 0
 PREC_BF16, PREC_FP16, PREC_BF16X3 = 1, 2, 3
 FMT_BF16, FMT_FP16 = 0, 1
-ACT_NONE, ACT_GELU, ACT_TANH = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_TANH, ACT_RELU, ACT_GELU_NEW = 0, 1, 2, 3, 4
 STEP_NONE, STEP_INIT, STEP_DDPM, STEP_EULER = 0, 1, 2, 3
 
 
@@ -56,6 +56,7 @@ class AttnArgs(C.Structure):
         ("K_hi", C.c_void_p), ("K_lo", C.c_void_p), ("ldk", C.c_int),
         ("V_hi", C.c_void_p), ("V_lo", C.c_void_p), ("ldv", C.c_int),
         ("O_hi", C.c_void_p), ("O_lo", C.c_void_p), ("ldo", C.c_int),
+        ("scale", C.c_float), ("pos_bias", C.c_void_p),
     ]
 
 
@@ -122,6 +123,8 @@ SYMBOLS = [
     ("didi_gemm_ln_stats_bytes", C.c_size_t, [C.c_int]),
     ("didi_gemm_ln", C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("didi_rmsnorm", C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    ("didi_mul_split", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     ("didi_round_argmax_bytes", C.c_size_t, [C.c_int, C.c_int]),
     ("didi_round_ce_bytes", C.c_size_t, [C.c_int, C.c_int]),
     ("didi_round_ce", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -156,8 +159,8 @@ def _load():
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.didi_version() != 2:
-        raise ImportError(f"libdidi_hip ABI version {lib.didi_version()} != 2")
+    if lib.didi_version() != 3:
+        raise ImportError(f"libdidi_hip ABI version {lib.didi_version()} != 3")
     return lib
 
 

@@ -53,8 +53,17 @@ def config_from_state_dict(sd, **overrides) -> DiDiConfig:
         c["enc_max_pos"] = sd["encoder.embeddings.position_embeddings.weight"].shape[0]
         c["enc_heads"] = max(1, c["enc_dim"] // 64)
         c["enc_ln_eps"] = 1e-12
-    elif any(k.startswith("encoder.block.") for k in sd):
-        raise ValueError("T5 context encoders (model.py:39-42) are not built (DESIGN.md section 5)")
+    elif "encoder.encoder.block.0.layer.0.SelfAttention.q.weight" in sd:  # T5EncoderModel (model.py:39-42)
+        q = "encoder.encoder.block.0.layer."
+        rel = sd[q + "0.SelfAttention.relative_attention_bias.weight"]  # [buckets, heads]
+        inner, c["enc_dim"] = sd[q + "0.SelfAttention.q.weight"].shape
+        c["enc_kind"] = "t5"
+        c["enc_layers"] = _n_layers(sd, r"encoder\.encoder\.block\.(\d+)\.")
+        c["enc_rel_buckets"], c["enc_heads"] = rel.shape
+        c["enc_dkv"] = inner // c["enc_heads"]
+        c["enc_ffn"] = sd[q + "1.DenseReluDense.wo.weight"].shape[1]
+        c["enc_gated_ffn"] = q + "1.DenseReluDense.wi_0.weight" in sd
+        c["enc_ln_eps"] = 1e-6
     else:
         raise ValueError("unrecognised context encoder in the state dict")
     has_adapter = "adapter.0.weight" in sd

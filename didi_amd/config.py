@@ -18,7 +18,7 @@ class DiDiConfig:
     dec_ffn: int = 3072
     dec_max_pos: int = 512
     dec_ln_eps: float = 1e-12
-    # context encoder: "blenderbot" (pre-LN) or "bert" (post-LN); T5 is not built
+    # context encoder: "blenderbot" (pre-LN), "bert" (post-LN) or "t5" (T5EncoderModel: RMSNorm, relative position bias)
     enc_kind: str = "blenderbot"
     enc_dim: int = 1280
     enc_layers: int = 2
@@ -27,6 +27,12 @@ class DiDiConfig:
     enc_max_pos: int = 128
     enc_scale_embedding: bool = True
     enc_ln_eps: float = 1e-5
+    # t5 only: per-head dim (heads * d_kv need not equal enc_dim), relative-position table, and whether the FFN is the
+    # v1.1 gated form (gelu_new(x wi_0) * (x wi_1)) or the original ReLU one
+    enc_dkv: int = 64
+    enc_rel_buckets: int = 32
+    enc_rel_max_distance: int = 128
+    enc_gated_ffn: bool = False
     pad_idx: int = 0
     # diffusion section (configs/train.yaml:25-31, model.py:85-87)
     diffusion_steps: int = 2000

@@ -32,6 +32,7 @@ struct AttnParams {
     int causal;
     float scale;  // 1/sqrt(D) * log2(e): the softmax runs in base 2
     const int32_t* key_mask;
+    const float* pos_bias;  // [heads][Sq][Sk] additive score bias (T5 relative positions) or null
     const u16* Q[2]; int ldq;
     const u16* K[2]; int ldk;
     const u16* V[2]; int ldv;
@@ -191,6 +192,14 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
                     sc[kt][1] = fmaf(acc[1], p.scale, m4.y);
                     sc[kt][2] = fmaf(acc[2], p.scale, m4.z);
                     sc[kt][3] = fmaf(acc[3], p.scale, m4.w);
+                    if (p.pos_bias && q < p.Sq) {  // the bias enters in natural-log units: scale by log2(e)
+                        const float* pb = p.pos_bias + ((size_t)head * p.Sq + q) * p.Sk;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int kk = kt * 16 + lg * 4 + r;
+                            if (kk < p.Sk) sc[kt][r] = fmaf(pb[kk], 1.4426950408889634f, sc[kt][r]);
+                        }
+                    }
                     if (p.causal && kt == qb) {  // only the diagonal tile holds future keys
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
@@ -287,6 +296,7 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
     if (a->D < 8 || a->D > 64 || a->D % 8 != 0 || a->Sq > 96 || a->Sk > 96) return DIDI_ERR_UNSUPPORTED;
     const int DP = a->D <= 32 ? 32 : 64;  // head dim padded to the MFMA K granularity
     if (a->causal && a->Sq != a->Sk) return DIDI_ERR_BAD_ARG;
+    DIDI_CHECK_ARG(a->scale >= 0.f && (reinterpret_cast<uintptr_t>(a->pos_bias) & 3) == 0);
     DIDI_CHECK_ARG(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo > 0 && a->ldo % 4 == 0);
     const bool x3 = a->precision == DIDI_PREC_BF16X3;
     const bool f16 = a->precision == DIDI_PREC_FP16;
@@ -299,7 +309,8 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
     AttnParams p{};
     p.B = a->B; p.heads = a->heads; p.Sq = a->Sq; p.Sk = a->Sk;
     p.causal = a->causal; p.d = a->D; p.key_mask = a->key_mask;
-    p.scale = 1.4426950408889634f / sqrtf((float)a->D);  // 1/sqrt(D) * log2(e)
+    p.scale = 1.4426950408889634f * (a->scale > 0.f ? a->scale : 1.0f / sqrtf((float)a->D));  // softmax scale * log2(e)
+    p.pos_bias = a->pos_bias;
     p.Q[0] = a->Q_hi; p.Q[1] = a->Q_lo; p.ldq = a->ldq;
     p.K[0] = a->K_hi; p.K[1] = a->K_lo; p.ldk = a->ldk;
     p.V[0] = a->V_hi; p.V[1] = a->V_lo; p.ldv = a->ldv;

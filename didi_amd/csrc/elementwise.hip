@@ -178,6 +178,84 @@ extern "C" int didi_layernorm(const float* x, const float* gamma, const float* b
     return DIDI_OK;
 }
 
+// ------------------------------------------------------------------ T5LayerNorm (RMS norm) and the gated-FFN product
+template <int MAXV>
+__global__ void __launch_bounds__(256) rmsnorm_kernel(const float* x, const float* gamma, float eps, int M, int H, u16* y_hi,
+                                                      u16* y_lo, float* y_f32, int f16) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const size_t row_off = (size_t)m * H;
+    float v[MAXV][4];
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+        if (c * 4 < H) {
+            const float4 t = reinterpret_cast<const float4*>(x + row_off)[c];
+            v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
+            q += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c * 4 < H) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+            const float y[4] = {v[j][0] * rstd * g.x, v[j][1] * rstd * g.y, v[j][2] * rstd * g.z, v[j][3] * rstd * g.w};
+            const size_t o = row_off + (size_t)c * 4;
+            if (y_f32) *reinterpret_cast<float4*>(y_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
+            if (y_hi) {
+                uint2 h, l;
+                split4(y, h, l, f16);
+                *reinterpret_cast<uint2*>(y_hi + o) = h;
+                if (y_lo) *reinterpret_cast<uint2*>(y_lo + o) = l;
+            }
+        }
+    }
+}
+
+extern "C" int didi_rmsnorm(const float* x, const float* gamma, float eps, int M, int H, uint16_t* y_hi, uint16_t* y_lo,
+                            float* y_f32, int plane_format, void* stream) {
+    DIDI_CHECK_ARG(x && gamma && (y_hi || y_f32) && M >= 0 && H > 0);
+    DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
+    const int f16 = plane_format == DIDI_FMT_FP16;
+    DIDI_CHECK_ARG(!(y_lo && !y_hi));
+    if (H % 4 != 0 || H > 2048) return DIDI_ERR_UNSUPPORTED;
+    if (M == 0) return DIDI_OK;
+    const int grid = cdiv(M, 4);
+    hipStream_t st = as_stream(stream);
+    if (H <= 256) rmsnorm_kernel<1><<<grid, 256, 0, st>>>(x, gamma, eps, M, H, y_hi, y_lo, y_f32, f16);
+    else if (H <= 768) rmsnorm_kernel<3><<<grid, 256, 0, st>>>(x, gamma, eps, M, H, y_hi, y_lo, y_f32, f16);
+    else if (H <= 1280) rmsnorm_kernel<5><<<grid, 256, 0, st>>>(x, gamma, eps, M, H, y_hi, y_lo, y_f32, f16);
+    else rmsnorm_kernel<8><<<grid, 256, 0, st>>>(x, gamma, eps, M, H, y_hi, y_lo, y_f32, f16);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+__global__ void __launch_bounds__(256) mul_split_kernel(const float* a, const float* b, size_t n4, u16* y_hi, u16* y_lo, int f16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 u = reinterpret_cast<const float4*>(a)[i], w = reinterpret_cast<const float4*>(b)[i];
+    const float y[4] = {u.x * w.x, u.y * w.y, u.z * w.z, u.w * w.w};
+    uint2 h, l;
+    split4(y, h, l, f16);
+    reinterpret_cast<uint2*>(y_hi)[i] = h;
+    if (y_lo) reinterpret_cast<uint2*>(y_lo)[i] = l;
+}
+
+extern "C" int didi_mul_split(const float* a, const float* b, size_t n, uint16_t* y_hi, uint16_t* y_lo, int plane_format,
+                              void* stream) {
+    DIDI_CHECK_ARG(a && b && y_hi && n % 4 == 0);
+    DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
+    if (n == 0) return DIDI_OK;
+    mul_split_kernel<<<(unsigned)cdiv((long)(n / 4), 256), 256, 0, as_stream(stream)>>>(a, b, n / 4, y_hi, y_lo, plane_format == DIDI_FMT_FP16);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
 // ------------------------------------------------------------------ sampler step + decoder prologue
 // bytes per row (H fp32 = 4H): DDPM reads x0 (4H) [+ eps 4H when injected], writes planes (4H)
 // [+ x_t 4H when traced]; the reference makes 3 elementwise passes + gather + add + LN passes.

@@ -299,6 +299,8 @@ __device__ __forceinline__ float erf_as(float x) {
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == DIDI_ACT_GELU) return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f));
     if (act == DIDI_ACT_TANH) return tanhf(v);
+    if (act == DIDI_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == DIDI_ACT_GELU_NEW) return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
     return v;
 }
 
@@ -1015,7 +1017,7 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
     DIDI_CHECK_ARG(al16(a->A_hi) && al16(a->A_lo) && al16(a->W_hi) && al16(a->W_lo) && al16(a->bias) && al16(a->R_f32));
     DIDI_CHECK_ARG(al8(a->R_hi) && al8(a->R_lo) && al16(a->C_f32) && al8(a->C_hi) && al8(a->C_lo));
     if (a->R_f32 || a->R_hi) DIDI_CHECK_ARG(a->ldr % 4 == 0 && a->ldr >= a->N);
-    DIDI_CHECK_ARG(a->act >= DIDI_ACT_NONE && a->act <= DIDI_ACT_TANH);
+    DIDI_CHECK_ARG(a->act >= DIDI_ACT_NONE && a->act <= DIDI_ACT_GELU_NEW);
     if (a->M == 0) return DIDI_OK;
     GemmParams p{};
     p.M = a->M; p.N = a->N; p.K = a->K;

@@ -173,6 +173,25 @@ class DiDiSampler:
                     fc2=_Planes(sd[p + "output.dense.weight"], sd[p + "output.dense.bias"], dev),
                     ln2=(f(p + "output.LayerNorm.weight"), f(p + "output.LayerNorm.bias")),
                 ))
+        elif cfg.enc_kind == "t5":  # T5EncoderModel (model.py:39-42): keys under encoder.encoder.*
+            q = "encoder.encoder."
+            e["tok"] = f(q + "embed_tokens.weight") if q + "embed_tokens.weight" in sd else f("encoder.shared.weight")
+            e["rel"] = f(q + "block.0.layer.0.SelfAttention.relative_attention_bias.weight")  # [buckets, heads]
+            e["layers"] = []
+            for i in range(cfg.enc_layers):
+                p = f"{q}block.{i}.layer."
+                qkv_w = torch.cat([sd[p + f"0.SelfAttention.{n}.weight"] for n in "qkv"], 0)
+                ly = dict(ln1=f(p + "0.layer_norm.weight"), qkv=_Planes(qkv_w, None, dev),
+                          out=_Planes(sd[p + "0.SelfAttention.o.weight"], None, dev), ln2=f(p + "1.layer_norm.weight"),
+                          wo=_Planes(sd[p + "1.DenseReluDense.wo.weight"], None, dev))
+                if cfg.enc_gated_ffn:
+                    ly["wi0"] = _Planes(sd[p + "1.DenseReluDense.wi_0.weight"], None, dev)
+                    ly["wi1"] = _Planes(sd[p + "1.DenseReluDense.wi_1.weight"], None, dev)
+                else:
+                    ly["wi"] = _Planes(sd[p + "1.DenseReluDense.wi.weight"], None, dev)
+                e["layers"].append(ly)
+            e["ln_f"] = f(q + "final_layer_norm.weight")
+            e["bias_cache"] = {}
         else:
             raise ValueError(f"Unsupported encoder kind: {cfg.enc_kind}")
         if cfg.has_adapter:  # model.py:122-123
@@ -205,6 +224,31 @@ class DiDiSampler:
                 f_hi, f_lo, _ = ly["fc1"](y_hi, y_lo, P, act="gelu")
                 _, _, h = ly["fc2"](f_hi, f_lo, P, residual=h, out_f32=True, out_planes=False)
             c_hi, c_lo, ctx = ops.layernorm(h, *e["ln_f"], cfg.enc_ln_eps, f32=True)
+        elif cfg.enc_kind == "t5":
+            inner = A * cfg.enc_dkv
+            bias = self._t5_position_bias(Cn)
+
+            def attn_t5(qkv_hi, qkv_lo):
+                v = lambda t, i: t.view(B, Cn, 3 * inner)[:, :, i * inner:(i + 1) * inner]  # noqa: E731
+                q, k, vv = ((v(qkv_hi, i), v(qkv_lo, i)) for i in range(3))
+                o_hi, o_lo = ops.attention(q, k, vv, A, causal=False, key_mask=mask32, precision=P, scale=1.0, pos_bias=bias)
+                return o_hi.view(B * Cn, inner), o_lo.view(B * Cn, inner)
+
+            h = ops.embed_gather(input_ids, e["tok"]).view(B * Cn, E)
+            for ly in e["layers"]:
+                y_hi, y_lo, _ = ops.rmsnorm(h, ly["ln1"], cfg.enc_ln_eps)
+                qkv_hi, qkv_lo, _ = ly["qkv"](y_hi, y_lo, P)
+                a_hi, a_lo = attn_t5(qkv_hi, qkv_lo)
+                _, _, h = ly["out"](a_hi, a_lo, P, residual=h, out_f32=True, out_planes=False)
+                y_hi, y_lo, _ = ops.rmsnorm(h, ly["ln2"], cfg.enc_ln_eps)
+                if cfg.enc_gated_ffn:
+                    _, _, g = ly["wi0"](y_hi, y_lo, P, act="gelu_new", out_f32=True, out_planes=False)
+                    _, _, u = ly["wi1"](y_hi, y_lo, P, out_f32=True, out_planes=False)
+                    f_hi, f_lo = ops.mul_split(g, u)
+                else:
+                    f_hi, f_lo, _ = ly["wi"](y_hi, y_lo, P, act="relu")
+                _, _, h = ly["wo"](f_hi, f_lo, P, residual=h, out_f32=True, out_planes=False)
+            c_hi, c_lo, ctx = ops.rmsnorm(h, e["ln_f"], cfg.enc_ln_eps, f32=True)
         else:
             x = ops.embed_gather(input_ids, e["tok"]).view(B * Cn, E)
             h_hi = torch.empty((B * Cn, E), dtype=torch.bfloat16, device=self.device)
@@ -225,6 +269,20 @@ class DiDiSampler:
             t_hi, t_lo, _ = e["ad0"](c_hi, c_lo, P, act="tanh")
             _, _, ctx = e["ad2"](t_hi, t_lo, P, out_f32=True, out_planes=False)
         return ctx.view(B, Cn, cfg.dec_dim)
+
+    def _t5_position_bias(self, c):
+        """[heads, C, C] fp32 relative position bias of T5Attention.compute_bias (HF:models/t5/modeling_t5.py:217-279),
+        bidirectional buckets; index arithmetic on the host (C <= 96), one gather of the block-0 table on the device."""
+        e, cfg = self._enc, self.cfg
+        if c not in e["bias_cache"]:
+            nb, max_exact = cfg.enc_rel_buckets // 2, cfg.enc_rel_buckets // 4
+            rel = torch.arange(c)[None, :] - torch.arange(c)[:, None]  # memory position - query position
+            rp = rel.abs()
+            large = max_exact + (torch.log(rp.float() / max_exact) / math.log(cfg.enc_rel_max_distance / max_exact) * (nb - max_exact)).to(torch.long)
+            large = torch.min(large, torch.full_like(large, nb - 1))
+            bucket = (rel > 0).long() * nb + torch.where(rp < max_exact, rp, large)
+            e["bias_cache"] = {c: e["rel"][bucket.to(self.device)].permute(2, 0, 1).contiguous()}
+        return e["bias_cache"][c]
 
     # ------------------------------------------------------------------ buffers + hoisted cross K/V
     @property

@@ -12,7 +12,8 @@ from . import _lib
 from ._lib import lib
 
 PRECISIONS = {"bf16": _lib.PREC_BF16, "fp16": _lib.PREC_FP16, "bf16x3": _lib.PREC_BF16X3}
-ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "gelu": _lib.ACT_GELU, "tanh": _lib.ACT_TANH}
+ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "gelu": _lib.ACT_GELU, "tanh": _lib.ACT_TANH, "relu": _lib.ACT_RELU,
+        "gelu_new": _lib.ACT_GELU_NEW}
 
 
 def _prec(p):
@@ -122,8 +123,9 @@ def gemm_ln(a_hi, a_lo, w_hi, w_lo, bias, residual_planes, gamma, beta, eps, pre
     return y_hi, y_lo, y
 
 
-def attention(q, k, v, heads, causal=False, key_mask=None, precision="bf16x3"):
-    """q/k/v: (hi, lo) plane pairs shaped [B, S, heads*D] (views with a row stride are fine)."""
+def attention(q, k, v, heads, causal=False, key_mask=None, precision="bf16x3", scale=None, pos_bias=None):
+    """q/k/v: (hi, lo) plane pairs shaped [B, S, heads*D] (views with a row stride are fine).
+    ``scale``: softmax scale (default 1/sqrt(D)); ``pos_bias``: fp32 [heads, Sq, Sk] added to the scaled scores (T5)."""
     B, Sq, HD = q[0].shape
     Sk = k[0].shape[1]
     a = _lib.AttnArgs()
@@ -138,8 +140,35 @@ def attention(q, k, v, heads, causal=False, key_mask=None, precision="bf16x3"):
     o_hi = torch.empty((B, Sq, HD), dtype=q[0].dtype, device=q[0].device)
     o_lo = torch.empty_like(o_hi) if a.precision == _lib.PREC_BF16X3 else None
     a.O_hi, a.O_lo, a.ldo = o_hi.data_ptr(), _lib.ptr(o_lo), HD
+    a.scale = 0.0 if scale is None else float(scale)
+    if pos_bias is not None:
+        assert pos_bias.dtype == torch.float32 and pos_bias.is_contiguous() and tuple(pos_bias.shape) == (heads, Sq, Sk)
+        a.pos_bias = pos_bias.data_ptr()
     _lib.check(lib.didi_attention(C.byref(a), _lib.current_stream()), "attention")
     return o_hi, o_lo
+
+
+def rmsnorm(x, gamma, eps, planes=True, need_lo=True, f32=False, dtype=torch.bfloat16):
+    """T5LayerNorm: x * rsqrt(mean(x^2) + eps) * gamma -> (hi, lo, f32) like ``layernorm``."""
+    x = _f32c(x)
+    M, H = x.numel() // x.shape[-1], x.shape[-1]
+    hi = torch.empty_like(x, dtype=dtype) if planes else None
+    lo = torch.empty_like(x, dtype=dtype) if planes and need_lo else None
+    y = torch.empty_like(x) if f32 else None
+    _lib.check(lib.didi_rmsnorm(x.data_ptr(), gamma.data_ptr(), eps, M, H, _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(y), _fmt(dtype),
+                                _lib.current_stream()), "rmsnorm")
+    return hi, lo, y
+
+
+def mul_split(a, b, need_lo=True, dtype=torch.bfloat16):
+    """(a * b) -> split planes."""
+    a, b = _f32c(a), _f32c(b)
+    assert a.shape == b.shape
+    hi = torch.empty_like(a, dtype=dtype)
+    lo = torch.empty_like(hi) if need_lo else None
+    _lib.check(lib.didi_mul_split(a.data_ptr(), b.data_ptr(), a.numel(), hi.data_ptr(), _lib.ptr(lo), _fmt(dtype),
+                                  _lib.current_stream()), "mul_split")
+    return hi, lo
 
 
 def round_argmax(x_hi, x_lo, w_hi, w_lo, precision="bf16x3"):

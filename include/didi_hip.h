@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DIDI_ABI_VERSION 2
+#define DIDI_ABI_VERSION 3
 
 enum {
     DIDI_OK = 0,
@@ -137,7 +137,9 @@ int didi_layernorm(const float* x, const float* gamma, const float* beta, float 
  *               residual: fp32 [M, ldr] or split planes (hi+lo), or none
  *   outputs   : any of fp32 C_f32 [M, ldc] and split planes C_hi/C_lo [M, ldc]
  * Constraints: K % 8 == 0, N % 4 == 0, lda/ldw % 8 == 0, ldc % 4 == 0, pointers 16-byte aligned. */
-enum { DIDI_ACT_NONE = 0, DIDI_ACT_GELU = 1, DIDI_ACT_TANH = 2 };
+enum { DIDI_ACT_NONE = 0, DIDI_ACT_GELU = 1, DIDI_ACT_TANH = 2,
+       DIDI_ACT_RELU = 3,     /* T5 DenseReluDense (HF:models/t5/modeling_t5.py T5DenseActDense) */
+       DIDI_ACT_GELU_NEW = 4  /* tanh form 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3))): T5 v1.1 gated FFN (T5DenseGatedActDense) */ };
 typedef struct didi_gemm_args {
     int M, N, K;
     int precision;
@@ -203,6 +205,14 @@ int didi_round_ce(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uin
  * `truncate_predictions` (src/sampling.py:104-113) without its per-row D2H sync. */
 int didi_first_eos(const int64_t* ids, int B, int S, int64_t eos_id, int32_t* lengths, void* stream);
 
+/* T5LayerNorm (HF:models/t5/modeling_t5.py): y = x * rsqrt(mean(x^2) + eps) * gamma, no mean subtraction, no bias.
+ * Same outputs and limits as didi_layernorm. */
+int didi_rmsnorm(const float* x, const float* gamma, float eps, int M, int H, uint16_t* y_hi, uint16_t* y_lo, float* y_f32,
+                 int plane_format, void* stream);
+
+/* y = a * b elementwise -> split planes (T5 v1.1's gated FFN: gelu_new(x wi_0^T) * (x wi_1^T)); n % 4 == 0. */
+int didi_mul_split(const float* a, const float* b, size_t n, uint16_t* y_hi, uint16_t* y_lo, int plane_format, void* stream);
+
 /* ---------------------------------------------------------------- attention */
 
 /* O[b, q, head] = softmax(Q K^T / sqrt(D) + mask) V for one layer, all (dialog, head) pairs:
@@ -229,6 +239,9 @@ typedef struct didi_attn_args {
     int ldv;
     uint16_t *O_hi, *O_lo;
     int ldo;
+    float scale;           /* softmax scale; 0 = 1/sqrt(D) (BERT, Blenderbot).  T5 passes 1: it folds the scale into its init */
+    const float* pos_bias; /* [heads][Sq][Sk] fp32 added to the scaled scores before the mask, or NULL: T5's relative
+                              position bias (HF:models/t5/modeling_t5.py T5Attention.compute_bias) */
 } didi_attn_args;
 int didi_attention(const didi_attn_args* a, void* stream);
 

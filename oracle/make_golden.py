@@ -115,6 +115,15 @@ def build_model(spec, seed, attn="eager"):
                                 dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, pad_token_id=0,
                                 attn_implementation=attn)
         encoder = BlenderbotEncoder(ecfg)
+    elif spec["enc_kind"] == "t5":
+        from transformers import T5Config, T5EncoderModel
+
+        ecfg = T5Config(vocab_size=V, d_model=spec["enc_dim"], d_kv=spec["enc_dkv"], d_ff=spec["enc_ffn"],
+                        num_layers=spec["enc_layers"], num_heads=spec["enc_heads"], dropout_rate=0.0,
+                        feed_forward_proj=spec["enc_ffn_act"], relative_attention_num_buckets=32,
+                        relative_attention_max_distance=128, is_encoder_decoder=False, use_cache=False, pad_token_id=0,
+                        attn_implementation=attn)
+        encoder = T5EncoderModel(ecfg)  # model.py:40-42
     else:
         ecfg = BertConfig(vocab_size=V, hidden_size=spec["enc_dim"], num_hidden_layers=spec["enc_layers"],
                           num_attention_heads=spec["enc_heads"], intermediate_size=spec["enc_ffn"],
@@ -173,6 +182,10 @@ TINY = dict(vocab=600, enc_kind="blenderbot", enc_dim=96, enc_layers=2, enc_head
             dec_dim=128, dec_layers=2, dec_heads=4, dec_ffn=512, T=20, schedule="sqrt")
 TINY_BERT = dict(vocab=600, enc_kind="bert", enc_dim=128, enc_layers=2, enc_heads=4, enc_ffn=256,
                  dec_dim=128, dec_layers=2, dec_heads=4, dec_ffn=512, T=10, schedule="cosine")
+TINY_T5 = dict(vocab=600, enc_kind="t5", enc_dim=96, enc_dkv=16, enc_layers=2, enc_heads=4, enc_ffn=256, enc_ffn_act="relu",
+               dec_dim=128, dec_layers=2, dec_heads=4, dec_ffn=512, T=10, schedule="sqrt")
+TINY_T5_GATED = dict(vocab=600, enc_kind="t5", enc_dim=128, enc_dkv=32, enc_layers=2, enc_heads=4, enc_ffn=192,
+                     enc_ffn_act="gated-gelu", dec_dim=128, dec_layers=2, dec_heads=4, dec_ffn=512, T=10, schedule="linear")
 CONFIG1 = dict(vocab=8008, enc_kind="blenderbot", enc_dim=128, enc_layers=2, enc_heads=4, enc_ffn=512,
                dec_dim=128, dec_layers=2, dec_heads=4, dec_ffn=512, T=50, schedule="sqrt")
 
@@ -197,9 +210,27 @@ def save_case(name, spec, run, logits, draws, calls, ctx, ids, mask, extra_meta=
     print(f"wrote {name}: {len(draws)} draws, {len(calls)} calls, logits {tuple(logits.shape)}")
 
 
+def t5_cases():
+    """(H) T5 context encoders (model.py:39-42): v1.0 ReLU FFN with an adapter, v1.1 gated-GELU FFN without one.
+    40-token contexts reach the logarithmic relative-position buckets."""
+    for name, spec, seed in (("tiny_t5enc_ddpm_f2", TINY_T5, 13), ("tiny_t5gated_euler_f3", TINY_T5_GATED, 14)):
+        m = build_model(spec, seed=seed)
+        with torch.no_grad():  # HF zero-inits nothing here, but the bias table starts tiny: widen it so it matters
+            m.encoder.encoder.block[0].layer[0].SelfAttention.relative_attention_bias.weight.mul_(4.0)
+        ids, mask = make_inputs(3, 40, spec["vocab"], seed=seed + 20)
+        run = dict(mode="ddpm" if "ddpm" in name else "euler", step_freq=2 if "ddpm" in name else 3, max_len=16, noise_seed=200 + seed)
+        logits, draws, calls = run_case(m, ids, mask, run["mode"], run["step_freq"], run["max_len"], run["noise_seed"])
+        ctx = m(encoder_input_ids=ids, encoder_attention_mask=mask, decoder_inputs_embeds=calls[0],
+                time_ids=torch.ones(3, 1, dtype=torch.long))[1]
+        save_case(name, spec, run, logits, draws, calls, ctx.detach(), ids, mask, weights=state_dict_of(m))
+
+
 def main():
     sys.path.insert(0, REF)
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "t5":  # add the T5 cases without regenerating the others
+        t5_cases()
+        return
     from src.diffusion.utils import configure_schedule
 
     # (F) schedules, straight from the reference
@@ -274,6 +305,7 @@ def main():
               metadata={"spec": json.dumps(CONFIG1), "run": json.dumps(run), "weights_sha256": sd_hash(w1),
                         "n_noise": str(len(draws)), "n_calls": str(len(calls)), "kept_calls": json.dumps(keep)})
     print("wrote config1_ddpm; weights sha256", sd_hash(w1)[:16])
+    t5_cases()
 
 
 if __name__ == "__main__":

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from .diffusion_math import configure_schedule
-from .transformer import bert_decoder, bert_encoder_model, blenderbot_encoder
+from .transformer import bert_decoder, bert_encoder_model, blenderbot_encoder, t5_encoder
 
 
 @dataclass
@@ -18,7 +18,7 @@ class OracleConfig:
     dec_dim: int = 768
     dec_layers: int = 12
     dec_heads: int = 12
-    enc_kind: str = "blenderbot"  # "blenderbot" | "bert"
+    enc_kind: str = "blenderbot"  # "blenderbot" | "bert" | "t5"
     enc_dim: int = 1280
     enc_layers: int = 2
     enc_heads: int = 32
@@ -29,7 +29,9 @@ class OracleConfig:
     s_tmin: float = 0.0
     s_tmax: float = float("inf")
     dec_ln_eps: float = 1e-12
-    enc_ln_eps: float = 1e-5  # blenderbot nn.LayerNorm default; bert encoder uses 1e-12
+    enc_ln_eps: float = 1e-5  # blenderbot nn.LayerNorm default; bert encoder uses 1e-12; t5 1e-6
+    enc_rel_buckets: int = 32  # t5 relative_attention_num_buckets / relative_attention_max_distance
+    enc_rel_max_distance: int = 128
 
 
 class _Table:
@@ -65,6 +67,9 @@ class OracleDiDi:
             )
         elif c.enc_kind == "bert":
             ctx = bert_encoder_model(self.sd, "encoder.", input_ids, attention_mask, c.enc_layers, c.enc_heads, 1e-12)
+        elif c.enc_kind == "t5":
+            ctx = t5_encoder(self.sd, "encoder.", input_ids, attention_mask, c.enc_layers, c.enc_heads, c.enc_rel_buckets,
+                             c.enc_rel_max_distance, c.enc_ln_eps)
         else:
             raise ValueError(f"Unsupported encoder kind: {c.enc_kind}")
         if self.has_adapter:  # Linear -> Tanh -> Linear, model.py:123,168-169

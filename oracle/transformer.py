@@ -11,6 +11,8 @@ following the installed 5.15.0 sources (``HF:`` = site-packages/transformers):
   bert_decoder        HF:models/bert/modeling_bert.py:594-718  (pooler output is discarded by the caller -> skipped)
   bert_encoder_model  same file, non-decoder BertModel used as the context encoder for "bert" base names
   blenderbot_encoder  HF:models/blenderbot/modeling_blenderbot.py:65-300,424-512 (pre-LN, learned pos, final LN)
+  t5_encoder          HF:models/t5/modeling_t5.py (T5LayerNorm, T5DenseActDense / T5DenseGatedActDense, T5Attention with
+                      the bucketed relative position bias :217-279, T5Stack): "t5" base names, model.py:39-42
 
 Masks follow the eager 4.30.2 formulation (additive ``finfo.min``): a fully masked key row gives
 a uniform softmax, never NaN.  All weights are read from a flat state dict with the reference's
@@ -127,3 +129,53 @@ def blenderbot_encoder(sd, prefix, input_ids, attention_mask, n_layers, n_heads,
         y = _ln(sd, p + "final_layer_norm", h, eps)
         h = r + _lin(sd, p + "fc2", F.gelu(_lin(sd, p + "fc1", y)))
     return _ln(sd, prefix + "layer_norm", h, eps)
+
+
+def t5_relative_position_bucket(relative_position, num_buckets=32, max_distance=128):
+    """Bidirectional bucketing of (memory_pos - query_pos) (HF:t5:217-262)."""
+    num_buckets //= 2
+    buckets = (relative_position > 0).to(torch.long) * num_buckets
+    rp = relative_position.abs()
+    max_exact = num_buckets // 2
+    is_small = rp < max_exact
+    large = max_exact + (torch.log(rp.float() / max_exact) / math.log(max_distance / max_exact) * (num_buckets - max_exact)).to(torch.long)
+    large = torch.min(large, torch.full_like(large, num_buckets - 1))
+    return buckets + torch.where(is_small, rp, large)
+
+
+def t5_position_bias(table, q_len, k_len, num_buckets=32, max_distance=128):
+    """[heads, q_len, k_len] from the block-0 ``relative_attention_bias.weight`` [num_buckets, heads] (HF:t5:264-279)."""
+    rel = torch.arange(k_len)[None, :] - torch.arange(q_len)[:, None]
+    return table[t5_relative_position_bucket(rel, num_buckets, max_distance)].permute(2, 0, 1).contiguous()
+
+
+def _rms(sd, key, x, eps):
+    """T5LayerNorm: no mean subtraction, no bias; variance in fp32."""
+    return sd[key] * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+
+
+def t5_encoder(sd, prefix, input_ids, attention_mask, n_layers, n_heads, num_buckets=32, max_distance=128, eps=1e-6):
+    """T5EncoderModel.last_hidden_state.  ``prefix`` addresses the T5EncoderModel ("encoder." in a DiDi checkpoint), whose
+    stack lives under ``encoder.``; the gated FFN (v1.1) is recognised by its ``wi_0`` weight.  No 1/sqrt(d) score scaling."""
+    st = prefix + "encoder."
+    h = F.embedding(input_ids, sd[st + "embed_tokens.weight"])
+    c = input_ids.shape[1]
+    bias = t5_position_bias(sd[st + "block.0.layer.0.SelfAttention.relative_attention_bias.weight"], c, c, num_buckets, max_distance)
+    add = bias[None] + key_padding_mask(attention_mask, h.dtype)
+    for i in range(n_layers):
+        a = f"{st}block.{i}.layer.0."
+        y = _rms(sd, a + "layer_norm.weight", h, eps)
+        q, k, v = (F.linear(y, sd[a + f"SelfAttention.{n}.weight"]) for n in "qkv")
+        inner = q.shape[-1]
+        q, k, v = (_heads(t, n_heads) for t in (q, k, v))
+        p = torch.softmax(torch.matmul(q, k.transpose(2, 3)) + add, dim=-1)
+        o = torch.matmul(p, v).transpose(1, 2).reshape(h.shape[0], c, inner)
+        h = h + F.linear(o, sd[a + "SelfAttention.o.weight"])
+        f = f"{st}block.{i}.layer.1."
+        y = _rms(sd, f + "layer_norm.weight", h, eps)
+        if f + "DenseReluDense.wi_0.weight" in sd:  # T5DenseGatedActDense, gelu_new
+            z = F.gelu(F.linear(y, sd[f + "DenseReluDense.wi_0.weight"]), approximate="tanh") * F.linear(y, sd[f + "DenseReluDense.wi_1.weight"])
+        else:  # T5DenseActDense, relu
+            z = torch.relu(F.linear(y, sd[f + "DenseReluDense.wi.weight"]))
+        h = h + F.linear(z, sd[f + "DenseReluDense.wo.weight"])
+    return _rms(sd, st + "final_layer_norm.weight", h, eps)

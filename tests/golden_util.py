@@ -54,7 +54,8 @@ def spec_to_config(spec) -> DiDiConfig:
         dec_ffn=spec["dec_ffn"], enc_kind=spec["enc_kind"], enc_dim=spec["enc_dim"], enc_layers=spec["enc_layers"],
         enc_heads=spec["enc_heads"], enc_ffn=spec["enc_ffn"], diffusion_steps=spec["T"], schedule=spec["schedule"],
         s_churn=spec.get("s_churn", 0.0), s_tmin=spec.get("s_tmin", 0.0), s_tmax=spec.get("s_tmax", float("inf")),
-        enc_ln_eps=1e-12 if spec["enc_kind"] == "bert" else 1e-5,
+        enc_ln_eps={"bert": 1e-12, "t5": 1e-6}.get(spec["enc_kind"], 1e-5),
+        enc_dkv=spec.get("enc_dkv", 64), enc_gated_ffn=spec.get("enc_ffn_act", "relu") == "gated-gelu",
     )
 
 
@@ -66,6 +67,7 @@ def spec_to_oracle_config(spec):
         enc_kind=spec["enc_kind"], enc_dim=spec["enc_dim"], enc_layers=spec["enc_layers"], enc_heads=spec["enc_heads"],
         diffusion_steps=spec["T"], schedule=spec["schedule"], s_churn=spec.get("s_churn", 0.0),
         s_tmin=spec.get("s_tmin", 0.0), s_tmax=spec.get("s_tmax", float("inf")),
+        enc_ln_eps={"bert": 1e-12, "t5": 1e-6}.get(spec["enc_kind"], 1e-5),
     )
 
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert getattr(raw, name) is not None
-    assert _lib.lib.didi_version() == 2
+    assert _lib.lib.didi_version() == 3
     assert b"workspace" in _lib.lib.didi_error_string(-4)
 
 

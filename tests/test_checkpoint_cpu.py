@@ -54,3 +54,18 @@ def test_load_state_reads_lightning_layout(tmp_path):
     torch.save(sd, bare)
     got, hp = load_state(bare)
     assert set(got) == set(sd) and hp == {}
+
+
+def test_t5_encoder_variants_inferred():
+    """T5EncoderModel checkpoints (model.py:39-42): family, head count, d_kv, FFN width and the gated form come from shapes."""
+    from golden_util import load_case, weights_of
+    from didi_amd.checkpoint import config_from_state_dict
+
+    for name, gated in (("tiny_t5enc_ddpm_f2", False), ("tiny_t5gated_euler_f3", True)):
+        t, meta = load_case(name)
+        spec = meta["spec"]
+        cfg = config_from_state_dict(weights_of(t), dec_heads=spec["dec_heads"])
+        assert cfg.enc_kind == "t5" and cfg.enc_gated_ffn == gated and cfg.enc_ln_eps == 1e-6
+        assert (cfg.enc_dim, cfg.enc_heads, cfg.enc_dkv, cfg.enc_ffn, cfg.enc_layers, cfg.enc_rel_buckets) == \
+            (spec["enc_dim"], spec["enc_heads"], spec["enc_dkv"], spec["enc_ffn"], spec["enc_layers"], 32)
+        assert cfg.has_adapter == (spec["enc_dim"] != spec["dec_dim"])

@@ -86,6 +86,28 @@ def test_layernorm(ops, M, H):
     assert torch.equal(hi.cpu(), y.cpu().to(torch.float16)) and rel_l2(ops.join(hi, lo), want) <= 2e-6
 
 
+@pytest.mark.parametrize("M,H", [(5, 96), (130, 128), (33, 768), (9, 2048)])
+def test_rmsnorm(ops, M, H):
+    """T5LayerNorm: x * rsqrt(mean(x^2) + eps) * gamma (no mean subtraction, no bias)."""
+    x = rnd(M, H, seed=M + H, scale=2.0) + 0.5
+    g = 1 + rnd(H, seed=1, scale=0.1)
+    want = x.double() * torch.rsqrt(x.double().pow(2).mean(-1, keepdim=True) + 1e-6) * g.double()
+    hi, lo, y = ops.rmsnorm(x.cuda(), g.cuda(), 1e-6, f32=True)
+    assert rel_l2(y, want) <= 1e-6
+    assert rel_l2(ops.join(hi, lo), want) <= 2e-5 and torch.equal(hi.cpu(), y.cpu().to(torch.bfloat16))
+    hi, lo, y = ops.rmsnorm(x.cuda(), g.cuda(), 1e-6, f32=True, dtype=torch.float16)
+    assert torch.equal(hi.cpu(), y.cpu().to(torch.float16)) and rel_l2(ops.join(hi, lo), want) <= 2e-6
+
+
+def test_mul_split(ops):
+    a, b = rnd(37, 192, seed=8), rnd(37, 192, seed=9)
+    hi, lo = ops.mul_split(a.cuda(), b.cuda())
+    assert rel_l2(ops.join(hi, lo), a.double() * b.double()) <= 2e-5
+    assert torch.equal(hi.cpu(), (a * b).to(torch.bfloat16))
+    hi, lo = ops.mul_split(a.cuda(), b.cuda(), need_lo=False, dtype=torch.float16)
+    assert lo is None and torch.equal(hi.cpu(), (a * b).to(torch.float16))
+
+
 def test_embed_gather(ops):
     table, pos = rnd(50, 96, seed=3), rnd(12, 96, seed=4)
     ids = torch.randint(0, 50, (3, 12), generator=torch.Generator().manual_seed(5))
@@ -153,6 +175,10 @@ def _gemm_ref(a, w, bias, act, resid):
         v = torch.nn.functional.gelu(v)
     elif act == "tanh":
         v = torch.tanh(v)
+    elif act == "relu":
+        v = torch.relu(v)
+    elif act == "gelu_new":
+        v = torch.nn.functional.gelu(v, approximate="tanh")
     if resid is not None:
         v = v + resid.double()
     return v
@@ -178,7 +204,7 @@ def test_gemm_plain(ops, M, N, K, precision):
     assert torch.equal(c_hi.cpu(), c.cpu().to(PD[precision]))
 
 
-@pytest.mark.parametrize("act", [None, "gelu", "tanh"])
+@pytest.mark.parametrize("act", [None, "gelu", "tanh", "relu", "gelu_new"])
 @pytest.mark.parametrize("resid", [None, "f32", "planes"])
 def test_gemm_epilogues(ops, act, resid):
     M, N, K = 150, 256, 192
@@ -419,6 +445,28 @@ def test_attention(ops, B, heads, Sq, Sk, d, causal, masked, precision):
         got, tol = o_hi.float(), (1.2e-2 if precision == "bf16" else 1.5e-3)  # P and O are additionally rounded to 16 bits
     assert rel_l2(got, want) <= tol, rel_l2(got, want)
     assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("B,heads,S,d", [(2, 4, 40, 16), (3, 4, 23, 32), (1, 8, 96, 64)])
+@pytest.mark.parametrize("precision", ALL_PREC)
+def test_attention_position_bias_and_scale(ops, B, heads, S, d, precision):
+    """T5Attention: softmax(q k^T * 1 + position_bias + mask) v -- explicit scale and an additive [heads, Sq, Sk] bias."""
+    HD = heads * d
+    qkv = rnd(B, S, 3 * HD, seed=S + d, scale=0.6)
+    bias = rnd(heads, S, S, seed=S, scale=2.0)
+    lens = torch.tensor([S, max(1, S // 3), 2][:B])
+    key_mask = (torch.arange(S)[None] < lens[:, None]).int()
+    x3 = precision == "bf16x3"
+    hi, lo = ops.split(qkv.cuda(), need_lo=x3, dtype=PD[precision])
+    parts = [(hi[:, :, i * HD:(i + 1) * HD], None if lo is None else lo[:, :, i * HD:(i + 1) * HD]) for i in range(3)]
+    o_hi, o_lo = ops.attention(*parts, heads, causal=False, key_mask=key_mask.cuda(), precision=precision, scale=1.0, pos_bias=bias.cuda())
+    f = (lambda t: t) if x3 else (lambda t: t.to(PD[precision]).float())
+    q, k, v = (f(qkv[:, :, i * HD:(i + 1) * HD]).double().view(B, S, heads, d).transpose(1, 2) for i in range(3))
+    sc = q @ k.transpose(2, 3) + bias.double()[None]
+    sc = sc.masked_fill(key_mask[:, None, None, :] == 0, torch.finfo(torch.float32).min)
+    want = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B, S, HD)
+    got, tol = (ops.join(o_hi, o_lo), 5e-5) if x3 else (o_hi.float(), 1.2e-2 if precision == "bf16" else 1.5e-3)
+    assert rel_l2(got, want) <= tol, rel_l2(got, want)
 
 
 def test_attention_all_keys_masked_is_uniform(ops):

@@ -38,14 +38,14 @@ def _model(weights, cfg, precision):
 TINY_CASES = ["tiny_ddpm_f1", "tiny_ddpm_f3_len8", "tiny_euler_f2", "tiny_euler_churn_f4"]
 
 
-@pytest.mark.parametrize("name", TINY_CASES + ["tiny_bertenc_ddpm_f2"])
+@pytest.mark.parametrize("name", TINY_CASES + ["tiny_bertenc_ddpm_f2", "tiny_t5enc_ddpm_f2", "tiny_t5gated_euler_f3"])
 @pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
 def test_golden_cases(name, precision):
     from didi_amd.sampling import sample
 
     t, meta = load_case(name)
     spec, run = meta["spec"], meta["run"]
-    w = weights_of(t) if name.startswith("tiny_bertenc") else weights_of(load_case("tiny_weights")[0])
+    w = weights_of(t) if name.startswith(("tiny_bertenc", "tiny_t5")) else weights_of(load_case("tiny_weights")[0])
     model = _model(w, spec_to_config(spec), precision)
     noise = torch.stack(noise_list(t, int(meta["n_noise"])))
     ctx = _ctx(t["in.input_ids"], t["in.attention_mask"])
@@ -65,7 +65,11 @@ def test_golden_cases(name, precision):
         assert match >= 0.999
     elif precision == "fp16":
         assert worst <= 1e-3 and lerr <= 2e-3
-        assert match >= 0.999
+        # >= 99.9 % of positions; the T5 cases have 48 positions, where ONE near-tie is 2 %: there an id may differ only
+        # where the reference's own top-2 logits are closer than twice our largest logit deviation
+        ref_top2 = t["out.logits"].topk(2, -1).values
+        near_tie = (ref_top2[..., 0] - ref_top2[..., 1]) <= 2 * (logits.cpu() - t["out.logits"]).abs().max()
+        assert match >= 0.999 or bool(((ids.cpu() == t["out.ids"]) | near_tie).all())
     else:
         assert worst <= 1e-2 and lerr <= 2e-2
         assert match >= 0.97

@@ -68,6 +68,20 @@ def test_bert_encoder_case():
     assert torch.equal(logits.argmax(-1), t["out.ids"])
 
 
+@pytest.mark.parametrize("name,adapter", [("tiny_t5enc_ddpm_f2", True), ("tiny_t5gated_euler_f3", False)])
+def test_t5_encoder_cases(name, adapter):
+    """T5EncoderModel contexts (model.py:39-42), ReLU and gated-GELU FFN, 40-token contexts (log-spaced position buckets):
+    the fixture comes from HF's T5EncoderModel under the reference sampler."""
+    t, meta, model, trace, logits = _run_case(name)
+    assert model.has_adapter == adapter
+    ctx = model.encode_context(t["in.input_ids"], t["in.attention_mask"])
+    assert rel_l2(ctx, t["out.context"]) <= 1e-5
+    for i, x in enumerate(trace):
+        assert rel_l2(x, t[f"xt.{i}"]) <= 1e-5
+    assert rel_l2(logits, t["out.logits"]) <= 1e-5
+    assert torch.equal(logits.argmax(-1), t["out.ids"])
+
+
 def test_config1_regenerated_weights():
     """BASELINE config 1: weights/noise regenerated from seeds, expected outputs from the reference run."""
     t, meta = load_case("config1_ddpm")

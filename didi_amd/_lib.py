@@ -123,6 +123,8 @@ SYMBOLS = [
     ("didi_gemm_ln_stats_bytes", C.c_size_t, [C.c_int]),
     ("didi_gemm_ln", C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("didi_gemm_small_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("didi_gemm_small", C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     ("didi_rmsnorm", C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     ("didi_mul_split", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     ("didi_round_argmax_bytes", C.c_size_t, [C.c_int, C.c_int]),

@@ -25,6 +25,7 @@ struct Carve {
     float* tmp;
     void* ln_stats;
     size_t ln_stats_bytes;
+    void* small_ws;  // split-K partial sums of the small-batch GEMM form (null when no shape of this batch uses it)
     size_t total;
 };
 
@@ -46,6 +47,10 @@ Carve carve(const didi_decoder* d, int B, int S, char* base) {
     c.tmp = (float*)take(M * H * 4);
     c.ln_stats_bytes = didi_gemm_ln_stats_bytes((int)M);
     c.ln_stats = take(c.ln_stats_bytes);
+    size_t small = 0;  // the six GEMM shapes of a layer
+    const int shapes[4][2] = {{3 * (int)H, (int)H}, {(int)H, (int)H}, {(int)I, (int)H}, {(int)H, (int)I}};
+    for (const auto& nk : shapes) small = std::max(small, didi_gemm_small_workspace_bytes((int)M, nk[0], nk[1], DIDI_PREC_BF16X3));
+    c.small_ws = small ? take(small) : nullptr;
     c.total = o;
     return c;
 }
@@ -67,8 +72,15 @@ struct Prof {
     }
 };
 
+// DIDI_GEMM_SMALL=0: A/B switch from the split-K small-batch form back to the plain 128x128 launch
+bool small_enabled() {
+    static const bool v = [] { const char* e = getenv("DIDI_GEMM_SMALL"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 int gemm(const didi_linear& w, int precision, int M, const u16* a_hi, const u16* a_lo, int lda, int act, const u16* r_hi,
-         const u16* r_lo, int ldr, float* c_f32, u16* c_hi, u16* c_lo, int ldc, void* stream, Prof* prof = nullptr) {
+         const u16* r_lo, int ldr, float* c_f32, u16* c_hi, u16* c_lo, int ldc, void* stream, Prof* prof = nullptr,
+         void* small_ws = nullptr) {
     didi_gemm_args g{};
     g.M = M; g.N = w.N; g.K = w.K; g.precision = precision;
     g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
@@ -77,7 +89,8 @@ int gemm(const didi_linear& w, int precision, int M, const u16* a_hi, const u16*
     g.R_hi = r_hi; g.R_lo = r_lo; g.ldr = ldr;
     g.C_f32 = c_f32; g.C_hi = c_hi; g.C_lo = c_lo; g.ldc = ldc;
     if (prof) prof->mark(stream);
-    const int rc = didi_gemm_bf16(&g, stream);
+    const bool small = small_ws && small_enabled() && ldc == w.N && didi_gemm_small_workspace_bytes(M, w.N, w.K, precision);
+    const int rc = small ? didi_gemm_small(&g, nullptr, nullptr, 0.f, small_ws, stream) : didi_gemm_bf16(&g, stream);
     if (prof) prof->mark(stream);
     return rc;
 }
@@ -86,7 +99,7 @@ int gemm(const didi_linear& w, int precision, int M, const u16* a_hi, const u16*
 // else GEMM -> fp32 tmp -> LayerNorm.  `epoch` tags this launch's statistics in the shared `stats` buffer.
 int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi, const u16* a_lo, int lda, const u16* r_hi,
             const u16* r_lo, int ldr, float* tmp, void* stats, uint32_t epoch, const float* gamma, const float* beta, float eps,
-            u16* y_hi, u16* y_lo, float* y_f32, void* stream, Prof* prof) {
+            u16* y_hi, u16* y_lo, float* y_f32, void* stream, Prof* prof, void* small_ws) {
     static const bool fuse = [] {  // DIDI_GEMM_LN=0: A/B switch back to GEMM + LayerNorm
         const char* e = getenv("DIDI_GEMM_LN");
         return !(e && e[0] == '0');
@@ -100,6 +113,19 @@ int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi
         g.R_hi = r_hi; g.R_lo = r_lo; g.ldr = ldr;
         if (prof) prof->mark(stream);
         const int rc = didi_gemm_ln(&g, gamma, beta, eps, y_hi, y_lo, y_f32, stats, epoch, stream);
+        if (prof) prof->mark(stream);
+        return rc;
+    }
+    if (small_ws && small_enabled() && didi_gemm_small_workspace_bytes(M, w.N, w.K, precision)) {  // LayerNorm rides in the row kernel
+        didi_gemm_args g{};
+        g.M = M; g.N = w.N; g.K = w.K; g.precision = precision;
+        g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
+        g.W_hi = w.w_hi; g.W_lo = w.w_lo; g.ldw = w.K;
+        g.bias = w.bias; g.act = DIDI_ACT_NONE;
+        g.R_hi = r_hi; g.R_lo = r_lo; g.ldr = ldr;
+        g.C_hi = y_hi; g.C_lo = y_lo; g.C_f32 = y_f32; g.ldc = w.N;
+        if (prof) prof->mark(stream);
+        const int rc = didi_gemm_small(&g, gamma, beta, eps, small_ws, stream);
         if (prof) prof->mark(stream);
         return rc;
     }
@@ -182,7 +208,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         const bool last = l == dec->L - 1;
         // --- causal self-attention block
         TRY(gemm(ly.qkv, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, w.qkv_hi,
-                 x3 ? w.qkv_lo : nullptr, 3 * H, stream, &prof));
+                 x3 ? w.qkv_lo : nullptr, 3 * H, stream, &prof, w.small_ws));
         didi_attn_args at{};
         at.B = a->B; at.heads = dec->heads; at.Sq = a->S; at.Sk = a->S; at.D = D; at.precision = prec;
         at.causal = 1; at.key_mask = nullptr;
@@ -192,11 +218,11 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.O_hi = w.att_hi; at.O_lo = x3 ? w.att_lo : nullptr; at.ldo = H;
         TRY(didi_attention(&at, stream));
         TRY(gemm_ln(ly.attn_out, prec, fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln1_g, ly.ln1_b,
-                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof));
+                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws));
         // --- cross-attention block (K/V hoisted: didi_decoder_prepare_context)
         u16* q_hi = w.qkv_hi;
         u16* q_lo = x3 ? w.qkv_lo : nullptr;
-        TRY(gemm(ly.cq, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream, &prof));
+        TRY(gemm(ly.cq, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream, &prof, w.small_ws));
         const size_t kvoff = (size_t)l * Mc * 2 * H;
         at.Sk = a->C; at.causal = 0; at.key_mask = a->ctx_mask;
         at.Q_hi = q_hi; at.Q_lo = q_lo; at.ldq = H;
@@ -204,14 +230,14 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;
         TRY(didi_attention(&at, stream));
         TRY(gemm_ln(ly.cross_out, prec, fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln2_g, ly.ln2_b,
-                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof));
+                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws));
         // --- feed-forward block
         TRY(gemm(ly.ffn_up, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_GELU, nullptr, nullptr, 0, nullptr, w.ffn_hi,
-                 x3 ? w.ffn_lo : nullptr, I, stream, &prof));
+                 x3 ? w.ffn_lo : nullptr, I, stream, &prof, w.small_ws));
         u16* o_hi = last && a->x0_hi ? a->x0_hi : w.h_hi;
         u16* o_lo = last && a->x0_hi ? a->x0_lo : w.h_lo;
         TRY(gemm_ln(ly.ffn_down, prec, fmt, M, w.ffn_hi, w.ffn_lo, I, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln3_g, ly.ln3_b,
-                    dec->ln_eps, o_hi, o_lo, last ? a->x0_f32 : nullptr, stream, &prof));
+                    dec->ln_eps, o_hi, o_lo, last ? a->x0_f32 : nullptr, stream, &prof, w.small_ws));
     }
     if (a->prof_used_host) *a->prof_used_host = prof.used;
     return DIDI_OK;

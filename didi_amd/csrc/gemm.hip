@@ -63,6 +63,7 @@ struct GemmParams {
     // argmax variant
     int tiles_m, tiles_n, nchunks, tiles_per_chunk;
     float2* partial;  // [M][nchunks] (value, index bits)
+    int k_split;               // split-K form (gemm_kernel, gridDim.y > 1): K columns per split; partial sums go to C_f32 + y*M*N
     float2* partial2;          // CE variant: [M][nchunks] (sum exp(logit - chunk max), target logit or -inf)
     const int64_t* targets;    // CE variant: [M] target ids
     // fused LayerNorm epilogue (gemm_pp_kernel<.., LN = true>): y = LayerNorm(acc + bias + residual) -> C_*
@@ -421,6 +422,12 @@ __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_kernel(GemmPara
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    if (p.k_split) {  // this workgroup multiplies K columns [y*k_split, ...) and writes raw partial sums
+        const int k0 = blockIdx.y * p.k_split;
+        p.A_hi += k0; p.A_lo += k0; p.W_hi += k0; p.W_lo += k0;
+        p.K = min(p.k_split, p.K - k0);
+        p.C_f32 += (size_t)blockIdx.y * p.M * p.ldc;
+    }
     f32x4 acc[4][4];
     gemm_tile<MODE, NSTAGE, F16>(p, smem, m0, n0, acc);
 
@@ -1030,7 +1037,8 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
     hipStream_t st = as_stream(stream);
     const int mode = pick_mode(p);
     const int big_tiles_n = cdiv(a->N, BBN);
-    const bool big = mode != 0 && gemm_big_enabled() && a->M >= 2048 && a->N >= BBN &&
+    static const int big_min_m = [] { const char* e = getenv("DIDI_BIG_MIN_M"); return e ? atoi(e) : 2048; }();  // tuning knob
+    const bool big = mode != 0 && gemm_big_enabled() && a->M >= big_min_m && a->N >= BBN &&
                      (long)big_tiles_n * BBN * 100 <= (long)a->N * 115;  // <= 15 % padded columns
     if (big) {
         if (!allow_big_lds()) return DIDI_ERR_LAUNCH;
@@ -1060,6 +1068,181 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
         else if (p.f16) gemm_kernel<0, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
         else gemm_kernel<0, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
     }
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ small batches: split-K GEMM + row epilogue
+// Below ~2048 rows the 128x128 grid holds a few dozen workgroups, each walking all of K alone: 24 us per launch at
+// M = 63 whatever the shape, with 90 % of the chip idle.  Here K is cut into chunks so that >= ~256 workgroups run, the
+// raw partial sums go to a workspace (L2-resident: <= 64 KiB per workgroup), and ONE row kernel adds them up and applies
+// bias, activation, residual and, for the output projections, LayerNorm -- so the separate LayerNorm pass goes away too.
+static int small_splits(int M, int N, int K, int precision) {
+    static const int max_m = [] { const char* e = getenv("DIDI_SMALL_MAX_M"); return e ? atoi(e) : 2048; }();  // tuning knob
+    if (M <= 0 || M >= max_m || N % 4 != 0 || N > 3072) return 0;
+    const int unit = 128;  // K columns per split are a multiple of this (two one-product K-tiles, four bf16x3 ones)
+    if (K % unit != 0 || K < 2 * unit) return 0;
+    if (precision != DIDI_PREC_BF16 && precision != DIDI_PREC_FP16 && precision != DIDI_PREC_BF16X3) return 0;
+    const int wgs = cdiv(M, BM) * cdiv(N, BN);
+    int ks = std::min(cdiv(256, wgs), K / unit);
+    if (ks < 2) return 0;
+    const int kc = cdiv(K / unit, ks) * unit;
+    return cdiv(K, kc);
+}
+
+extern "C" size_t didi_gemm_small_workspace_bytes(int M, int N, int K, int precision) {
+    const int ks = small_splits(M, N, K, precision);
+    return ks ? (size_t)ks * M * N * sizeof(float) : 0;
+}
+
+// One thread per 4 output columns: sum the K-split partials (independent loads, all in flight), bias, activation, residual.
+// LN = false: a flat elementwise grid.  LN = true: one 256-thread workgroup per row (CH chunks per thread, N <= 1024 * CH),
+// two-pass mean / variance through a wave + LDS reduction, as layernorm_kernel computes them.
+struct RowsParams {
+    const float* part; int ks, M, N;
+    const float* bias; int act;
+    const u16 *r_hi, *r_lo; const float* r_f32; int ldr;
+    const float *gamma, *beta; float eps;
+    u16 *y_hi, *y_lo; float* y_f32; int f16;
+};
+
+__device__ __forceinline__ float4 rows_value(const RowsParams& p, int m, int c) {
+    const size_t plane = (size_t)p.M * p.N;
+    const float* src = p.part + (size_t)m * p.N + (size_t)c * 4;
+    float4 a = *reinterpret_cast<const float4*>(src);
+    float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int z = 1;
+    for (; z + 1 < p.ks; z += 2) {  // two independent chains keep the loads in flight
+        const float4 b = *reinterpret_cast<const float4*>(src + z * plane), d = *reinterpret_cast<const float4*>(src + (z + 1) * plane);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        a2.x += d.x; a2.y += d.y; a2.z += d.z; a2.w += d.w;
+    }
+    if (z < p.ks) {
+        const float4 b = *reinterpret_cast<const float4*>(src + z * plane);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+    if (p.bias) {
+        const float4 b = reinterpret_cast<const float4*>(p.bias)[c];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (p.act != DIDI_ACT_NONE) { a.x = act_apply(a.x, p.act); a.y = act_apply(a.y, p.act); a.z = act_apply(a.z, p.act); a.w = act_apply(a.w, p.act); }
+    if (p.r_f32) {
+        const float4 r = *reinterpret_cast<const float4*>(p.r_f32 + (size_t)m * p.ldr + c * 4);
+        a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+    } else if (p.r_hi) {
+        float r[4];
+        unpack4(*reinterpret_cast<const uint2*>(p.r_hi + (size_t)m * p.ldr + c * 4), r, p.f16);
+        a.x += r[0]; a.y += r[1]; a.z += r[2]; a.w += r[3];
+        if (p.r_lo) {
+            unpack4(*reinterpret_cast<const uint2*>(p.r_lo + (size_t)m * p.ldr + c * 4), r, p.f16);
+            a.x += r[0]; a.y += r[1]; a.z += r[2]; a.w += r[3];
+        }
+    }
+    return a;
+}
+
+__device__ __forceinline__ void rows_store(const RowsParams& p, int m, int c, const float (&y)[4]) {
+    const size_t o = (size_t)m * p.N + (size_t)c * 4;
+    if (p.y_f32) *reinterpret_cast<float4*>(p.y_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
+    if (p.y_hi) {
+        uint2 h, l;
+        split4(y, h, l, p.f16);
+        *reinterpret_cast<uint2*>(p.y_hi + o) = h;
+        if (p.y_lo) *reinterpret_cast<uint2*>(p.y_lo + o) = l;
+    }
+}
+
+__global__ void __launch_bounds__(256) splitk_sum_kernel(RowsParams p) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int nc = p.N / 4;
+    if (i >= (size_t)p.M * nc) return;
+    const int m = (int)(i / nc), c = (int)(i % nc);
+    const float4 a = rows_value(p, m, c);
+    const float y[4] = {a.x, a.y, a.z, a.w};
+    rows_store(p, m, c, y);
+}
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {  // red: 4 floats of LDS; all 256 threads call it
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();  // the previous use of red is over
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int CH>
+__global__ void __launch_bounds__(256) splitk_ln_kernel(RowsParams p) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, nc = p.N / 4;
+    float v[CH][4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+        if (c < nc) {
+            const float4 a = rows_value(p, m, c);
+            v[j][0] = a.x; v[j][1] = a.y; v[j][2] = a.z; v[j][3] = a.w;
+            s += (a.x + a.y) + (a.z + a.w);
+        }
+    }
+    const float mean = block_sum256(s, red) / (float)p.N;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+        if (threadIdx.x + 256 * j < nc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q += d * d; }
+        }
+    const float rstd = 1.0f / sqrtf(block_sum256(q, red) / (float)p.N + p.eps);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < nc) {
+            const float4 g = reinterpret_cast<const float4*>(p.gamma)[c], b = reinterpret_cast<const float4*>(p.beta)[c];
+            const float y[4] = {(v[j][0] - mean) * rstd * g.x + b.x, (v[j][1] - mean) * rstd * g.y + b.y,
+                                (v[j][2] - mean) * rstd * g.z + b.z, (v[j][3] - mean) * rstd * g.w + b.w};
+            rows_store(p, m, c, y);
+        }
+    }
+}
+
+extern "C" int didi_gemm_small(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, void* workspace,
+                               void* stream) {
+    DIDI_CHECK_ARG(a && a->A_hi && a->W_hi && workspace && (a->C_f32 || a->C_hi) && !(a->C_lo && !a->C_hi));
+    DIDI_CHECK_ARG((gamma == nullptr) == (beta == nullptr));
+    const int ks = small_splits(a->M, a->N, a->K, a->precision);
+    if (!ks || a->ldc != a->N) return DIDI_ERR_UNSUPPORTED;
+    DIDI_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K);
+    DIDI_CHECK_ARG(al16(a->A_hi) && al16(a->A_lo) && al16(a->W_hi) && al16(a->W_lo) && al16(a->bias) && al16(a->R_f32) && al16(workspace));
+    DIDI_CHECK_ARG(al8(a->R_hi) && al8(a->R_lo) && al16(a->C_f32) && al8(a->C_hi) && al8(a->C_lo) && al16(gamma) && al16(beta));
+    if (a->R_f32 || a->R_hi) DIDI_CHECK_ARG(a->ldr % 4 == 0 && a->ldr >= a->N);
+    DIDI_CHECK_ARG(a->act >= DIDI_ACT_NONE && a->act <= DIDI_ACT_GELU_NEW);
+    GemmParams p{};
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    int rc = fill_operands(p, a->precision, a->A_hi, a->A_lo, a->W_hi, a->W_lo);
+    if (rc != DIDI_OK) return rc;
+    p.lda = a->lda; p.ldw = a->ldw; p.act = DIDI_ACT_NONE;
+    p.C_f32 = reinterpret_cast<float*>(workspace); p.ldc = a->N;
+    p.k_split = cdiv(a->K / 128, ks) * 128;
+    p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(p.tiles_m * p.tiles_n, ks);
+    if (p.npass == 3) gemm_kernel<3, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
+    else if (p.f16) gemm_kernel<1, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
+    else gemm_kernel<1, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
+    DIDI_LAUNCH_CHECK();
+    RowsParams r{};
+    r.part = reinterpret_cast<const float*>(workspace); r.ks = ks; r.M = a->M; r.N = a->N;
+    r.bias = a->bias; r.act = a->act;
+    r.r_hi = a->R_hi; r.r_lo = a->R_lo; r.r_f32 = a->R_f32; r.ldr = a->ldr;
+    r.gamma = gamma; r.beta = beta; r.eps = eps;
+    r.y_hi = a->C_hi; r.y_lo = a->C_lo; r.y_f32 = a->C_f32; r.f16 = a->precision == DIDI_PREC_FP16;
+    if (!gamma) splitk_sum_kernel<<<cdiv((long)a->M * (a->N / 4), 256), 256, 0, st>>>(r);
+    else if (a->N <= 1024) splitk_ln_kernel<1><<<a->M, 256, 0, st>>>(r);
+    else if (a->N <= 2048) splitk_ln_kernel<2><<<a->M, 256, 0, st>>>(r);
+    else splitk_ln_kernel<3><<<a->M, 256, 0, st>>>(r);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

@@ -78,7 +78,7 @@ def layernorm(x, gamma, beta, eps, planes=True, need_lo=True, f32=False, dtype=t
 
 
 def gemm(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, precision="bf16x3", residual=None, residual_planes=None,
-         out_f32=False, out_planes=True, out_lo=True):
+         out_f32=False, out_planes=True, out_lo=True, small=None):
     """C = act(A W^T + bias) + residual.  A planes [M,K], W planes [N,K].  -> (C_hi, C_lo, C_f32)."""
     M, K = a_hi.shape
     N = w_hi.shape[0]
@@ -98,7 +98,15 @@ def gemm(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, precision="bf16x3", residu
     c_hi = torch.empty((M, N), dtype=pd, device=dev) if out_planes else None
     c_lo = torch.empty((M, N), dtype=pd, device=dev) if out_planes and out_lo else None
     g.C_f32, g.C_hi, g.C_lo, g.ldc = _lib.ptr(c_f32), _lib.ptr(c_hi), _lib.ptr(c_lo), N
-    _lib.check(lib.didi_gemm_bf16(C.byref(g), _lib.current_stream()), "gemm")
+    if small is not None:  # split-K small-batch form; `small` = (gamma, beta, eps) for a LayerNorm over the columns, or ()
+        ws_bytes = lib.didi_gemm_small_workspace_bytes(M, N, K, g.precision)
+        if ws_bytes == 0:
+            raise _lib.DidiHipError(f"the small-batch GEMM form does not apply to M={M} N={N} K={K}")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        gamma, beta, eps = small if small else (None, None, 0.0)
+        _lib.check(lib.didi_gemm_small(C.byref(g), _lib.ptr(gamma), _lib.ptr(beta), eps, ws.data_ptr(), _lib.current_stream()), "gemm_small")
+    else:
+        _lib.check(lib.didi_gemm_bf16(C.byref(g), _lib.current_stream()), "gemm")
     return c_hi, c_lo, c_f32
 
 

@@ -179,6 +179,14 @@ size_t didi_gemm_ln_stats_bytes(int M);
 int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, uint16_t* y_hi,
                  uint16_t* y_lo, float* y_f32, void* stats, uint32_t epoch, void* stream);
 
+/* Small batches (M < 2048 rows: interactive use, a handful of dialogs).  The same arithmetic as didi_gemm_bf16 (+ an
+ * optional LayerNorm over the N output columns: gamma/beta non-NULL, as didi_gemm_ln), organised for latency: K is split
+ * over workgroups, the partial sums go through `workspace` (didi_gemm_small_workspace_bytes(M, N, K, precision) bytes,
+ * 16-byte aligned; 0 = this form does not apply, use didi_gemm_bf16), and one row kernel applies bias, activation,
+ * residual, LayerNorm and writes the outputs (ldc == N).  N <= 3072, N % 4 == 0, K % 128 == 0. */
+size_t didi_gemm_small_workspace_bytes(int M, int N, int K, int precision);
+int didi_gemm_small(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, void* workspace, void* stream);
+
 /* ids[m] = argmax_n sum_p X_p[m,:] . Wc_p[n,:]  -- the "rounding" step
  * `model.classifier(x_0)` + `logits.argmax(-1)` (src/sampling.py:64,82,32) without ever writing
  * the [M, V] logits.  First (lowest) index wins ties, as torch.argmax on CPU.  Two launches:

@@ -226,6 +226,47 @@ def test_gemm_epilogues(ops, act, resid):
     assert rel_l2(c, _gemm_ref(a, w, None, None, None)) <= 3e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(63, 768, 768), (63, 2304, 768), (1, 3072, 768), (504, 768, 3072), (130, 128, 256), (2016, 768, 768)])
+@pytest.mark.parametrize("precision", ALL_PREC)
+@pytest.mark.parametrize("ln", [False, True])
+def test_gemm_small_batch_form(ops, M, N, K, precision, ln):
+    """didi_gemm_small (split-K + row epilogue) == [LayerNorm](gelu(A W^T + bias) + residual) on the same rounded operands, and
+    agrees with the plain launch of didi_gemm_bf16 to summation-order rounding."""
+    from didi_amd._lib import lib
+
+    a, w, bias, r = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=0.05), rnd(N, seed=43), rnd(M, N, seed=44)
+    g, b = 1 + rnd(N, seed=45, scale=0.1), rnd(N, seed=46, scale=0.1)
+    pd, x3 = PD[precision], precision == "bf16x3"
+    assert lib.didi_gemm_small_workspace_bytes(M, N, K, ops.PRECISIONS[precision]) > 0
+    a_hi, a_lo = ops.split(a.cuda(), dtype=pd)
+    w_hi, w_lo = ops.split(w.cuda(), dtype=pd)
+    rp = ops.split(r.cuda(), dtype=pd)
+    act = None if ln else "gelu"
+    small = (g.cuda(), b.cuda(), 1e-12) if ln else ()
+    c_hi, c_lo, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), act=act, precision=precision, residual_planes=rp,
+                             out_f32=True, small=small)
+    ar, wr = (ops.join(a_hi, a_lo).cpu(), ops.join(w_hi, w_lo).cpu()) if x3 else (a_hi.cpu().float(), w_hi.cpu().float())
+    want = _gemm_ref(ar, wr, bias, act, ops.join(*rp).cpu())
+    if ln:
+        want = torch.nn.functional.layer_norm(want, (N,), g.double(), b.double(), 1e-12)
+    assert rel_l2(c, want) <= 5e-6, rel_l2(c, want)
+    assert torch.equal(c_hi.cpu(), c.cpu().to(pd)) and rel_l2(ops.join(c_hi, c_lo), c) <= 2e-5
+    if not ln:
+        _, _, plain = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), act=act, precision=precision, residual_planes=rp,
+                               out_f32=True, out_planes=False)
+        assert rel_l2(c, plain) <= 2e-6
+
+
+def test_gemm_small_batch_form_limits(ops):
+    from didi_amd._lib import lib
+
+    P = ops.PRECISIONS["fp16"]
+    assert lib.didi_gemm_small_workspace_bytes(16384, 768, 768, P) == 0   # large batches fill the chip without a split
+    assert lib.didi_gemm_small_workspace_bytes(2016, 3072, 768, P) == 0   # 384 workgroups already
+    assert lib.didi_gemm_small_workspace_bytes(63, 768, 96, P) == 0       # K not a multiple of 128
+    assert lib.didi_gemm_small_workspace_bytes(63, 8008, 768, P) == 0     # wider than the row kernel holds
+
+
 @pytest.mark.parametrize("M,N,K", [(2304, 768, 768), (2100, 2304, 768), (2048, 8008, 768), (2050, 576, 3072), (4096, 3072, 128)])
 @pytest.mark.parametrize("precision", ALL_PREC)
 def test_gemm_big_tile(ops, M, N, K, precision):

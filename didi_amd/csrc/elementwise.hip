@@ -35,11 +35,12 @@ __device__ __forceinline__ void philox_normal4(uint64_t ctr, uint64_t seed, floa
     for (int p = 0; p < 2; ++p) {
         const float u1 = ((float)r[2 * p] + 0.5f) * k;  // (0, 1]
         const float u2 = ((float)r[2 * p + 1] + 0.5f) * k;
-        const float rad = sqrtf(-2.0f * logf(u1));
-        float s, c;
-        sincosf(6.283185307179586f * u2, &s, &c);
-        z[2 * p] = rad * c;
-        z[2 * p + 1] = rad * s;
+        // hardware transcendentals: v_log_f32 (log2), v_sin/v_cos_f32 (argument in revolutions, so 2*pi*u2 is never formed).
+        // The library logf/sincosf cost this kernel a third of its run time (34 -> 2x us at cfg2) for digits the noise does not need;
+        // against the numpy oracle the normals differ by < 5e-5 absolute (tests/test_gpu_kernels.py).
+        const float rad = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+        z[2 * p] = rad * __builtin_amdgcn_cosf(u2);
+        z[2 * p + 1] = rad * __builtin_amdgcn_sinf(u2);
     }
 }
 

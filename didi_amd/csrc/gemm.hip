@@ -600,7 +600,11 @@ __global__ void __launch_bounds__(BigGeom<MT>::THREADS, 2) gemm_big_kernel(GemmP
 //                                                                   into buffer i&1, waits for A(i+1)
 // The activation pieces (the ones that can miss L2) get 1.5 K-tiles of flight, the weight pieces
 // (L2 hits) one; every DMA wait is a counted vmcnt followed by a barrier before the first read.
-template <int NPASS, bool F16, bool LN>
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi);  // argmax order: larger value, then lower index
+
+// AMAX: the rounding form.  No output tile: each row's (max, index) over this tile's 192 vocabulary columns goes to
+// p.partial[m][tile column]; the logits never leave the registers.
+template <int NPASS, bool F16, bool LN, bool AMAX = false>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     using G = BigGeom<4>;
     constexpr int BKK = NPASS == 3 ? 32 : 64;
@@ -758,6 +762,49 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #undef PP_ISSUE
 #undef PP_READ
 #undef PP_MFMA
+    if constexpr (AMAX) {
+        // lane (lr, lg) of wave (wm, wn) holds, for row wm*64 + mi*16 + lr, the columns wn*96 + 32k + 8lg + 4h + r of tile ni = 2k + h
+        float best[4];
+        int bidx[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            best[mi] = -INFINITY; bidx[mi] = 0x7fffffff;
+#pragma unroll
+            for (int ni = 0; ni < 6; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * 96 + 32 * (ni >> 1) + 8 * lg + 4 * (ni & 1) + r;
+                    const float v = acc[ni][mi][r];
+                    if (n < p.N && better(v, n, best[mi], bidx[mi])) { best[mi] = v; bidx[mi] = n; }
+                }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ov = __shfl_xor(best[mi], o, 64);
+                const int oi = __shfl_xor(bidx[mi], o, 64);
+                if (better(ov, oi, best[mi], bidx[mi])) { best[mi] = ov; bidx[mi] = oi; }
+            }
+        }
+        float* rv = reinterpret_cast<float*>(smem);        // [256] the wn = 1 half's result per row (the stages are free now)
+        int* ri = reinterpret_cast<int*>(smem + 1024);     // [256]
+        if (wn == 1 && lg == 0) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) { rv[wm * 64 + mi * 16 + lr] = best[mi]; ri[wm * 64 + mi * 16 + lr] = bidx[mi]; }
+        }
+        __syncthreads();
+        if (wn == 0 && lg == 0) {
+            const int tn = tile % p.tiles_n;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int ml = wm * 64 + mi * 16 + lr, m = m0 + ml;
+                if (m < p.M) {
+                    float v = best[mi]; int i = bidx[mi];
+                    if (better(rv[ml], ri[ml], v, i)) { v = rv[ml]; i = ri[ml]; }
+                    p.partial[(size_t)m * p.nchunks + tn] = make_float2(v, __int_as_float(i));
+                }
+            }
+        }
+        return;
+    }
     const float2* gelu_tbl = use_lut ? reinterpret_cast<const float2*>(smem + 2 * STAGE) : nullptr;
     // residual planes: all 12 loads of half a wave tile are issued before the first use (the fragment
     // registers are dead by now), instead of one exposed memory round trip per 8 columns
@@ -1517,6 +1564,26 @@ static int round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const
     int rc = fill_operands(p, precision, X_hi, X_lo, W_hi, W_lo);
     if (rc != DIDI_OK) return rc;
     p.lda = ldx; p.ldw = ldw;
+    hipStream_t st = as_stream(stream);
+    if (!ce && M >= 2048 && K >= 128 && pick_mode(p) != 0 && gemm_pp_enabled() && gemm_big_enabled()) {
+        // large batches: the 256x192 staggered loop with the argmax epilogue, one workgroup per (row band, 192 vocabulary columns)
+        static const bool ok = allow_big_lds() &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<3, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess;
+        if (!ok) return DIDI_ERR_LAUNCH;
+        p.tiles_m = cdiv(M, 256); p.tiles_n = cdiv(V, BBN); p.nchunks = p.tiles_n;
+        p.partial = reinterpret_cast<float2*>(partial);
+        const int grid = p.tiles_m * p.tiles_n;
+        const size_t lds = 2 * BigGeom<4>::STAGE + 8192;
+        if (p.npass == 3) gemm_pp_kernel<3, false, false, true><<<grid, 512, lds, st>>>(p);
+        else if (p.f16) gemm_pp_kernel<1, true, false, true><<<grid, 512, lds, st>>>(p);
+        else gemm_pp_kernel<1, false, false, true><<<grid, 512, lds, st>>>(p);
+        DIDI_LAUNCH_CHECK();
+        argmax_reduce_kernel<<<cdiv(M, 256), 256, 0, st>>>(p.partial, M, p.nchunks, V, ids64, ids32);
+        DIDI_LAUNCH_CHECK();
+        return DIDI_OK;
+    }
     p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(V, BN);
     int nchunks = cdiv(1024, p.tiles_m);  // aim at >= 4 workgroups per CU
     if (nchunks > p.tiles_n) nchunks = p.tiles_n;
@@ -1526,7 +1593,6 @@ static int round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const
     p.partial = reinterpret_cast<float2*>(partial);
     p.partial2 = p.partial + (size_t)M * cdiv(V, BN);  // second half of didi_round_ce_bytes
     p.targets = targets;
-    hipStream_t st = as_stream(stream);
     const int grid = p.tiles_m * p.nchunks;
 #define DIDI_ROUND_LAUNCH(CE_)                                                                           \
     switch (pick_mode(p)) {                                                                              \

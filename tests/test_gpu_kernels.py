@@ -361,7 +361,8 @@ def test_gemm_rejects_bad_shapes(ops):
 
 
 # ------------------------------------------------------------------ rounding (classifier + argmax)
-@pytest.mark.parametrize("M,V,K", [(184, 8008, 128), (77, 600, 128), (300, 8008, 768), (5, 130, 64), (168, 50000, 768)])
+@pytest.mark.parametrize("M,V,K", [(184, 8008, 128), (77, 600, 128), (300, 8008, 768), (5, 130, 64), (168, 50000, 768),
+                                   (2304, 8008, 768), (2100, 1000, 128), (2048, 50000, 768)])  # >= 2048 rows: the 256x192 kernel
 @pytest.mark.parametrize("precision", ALL_PREC)
 def test_round_argmax(ops, M, V, K, precision):
     x, w = rnd(M, K, seed=11), rnd(V, K, seed=12, scale=0.02)
@@ -381,8 +382,9 @@ def test_round_argmax(ops, M, V, K, precision):
     assert ((top2[:, 0] - picked).abs() <= 1e-4 * top2[:, 0].abs().clamp_min(1e-3)).all()
 
 
-def test_round_argmax_first_index_wins_ties(ops):
-    M, V, K = 40, 700, 64
+@pytest.mark.parametrize("M", [40, 2100])
+def test_round_argmax_first_index_wins_ties(ops, M):
+    V, K = 700, 128
     x, w = rnd(M, K, seed=13), rnd(V, K, seed=14, scale=0.05)
     w[650] = w[3]
     w[400] = w[3]

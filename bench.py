@@ -172,7 +172,7 @@ def main():
             traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
             traffic_src = os.path.relpath(tpath, ROOT)
         roofline = {
-            "bound": "mfma", "kernel": (f"gemm_pp_kernel<{3 if args.precision == 'bf16x3' else 1}, {'true' if args.precision == 'fp16' else 'false'}, LN> "
+            "bound": "mfma", "kernel": (f"gemm_pp_kernel<{3 if args.precision == 'bf16x3' else 1}, {'true' if args.precision == 'fp16' else 'false'}, LN, false> "
                                          "(256x192 tile, staggered wave groups; LN=true on the three output projections per layer, "
                                          "which carry bias + residual + LayerNorm in the epilogue)"),
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,

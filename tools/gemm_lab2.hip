@@ -125,16 +125,35 @@ __global__ void __launch_bounds__(512, 2) lab2_kernel(P p, int ntiles) {
     (void)np;
     for (; tile < last; tile += step) {
         const int m0 = (tile / p.tiles_n) * BMM, n0 = (tile % p.tiles_n) * BNN;
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 acc[6][4];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 wf[2][6], af[2][4];
+        // the two wave groups run SEPARATE copies of the tile body (loop, next-tile issue, epilogue): accumulators and fragments
+        // then live and die inside one branch and nothing is merged at the tile loop's back-edge
+#define ZERO_ACC()                                                                  \
+        f32x4 acc[6][4];                                                            \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i)                               \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+        bf16x8 wf[2][6], af[2][4];                                                  \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) { wf[0][i] = wf[1][i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { af[0][i] = af[1][i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+#define NEXT_ISSUE()                                                                \
+        if (tile + step < last) {                                                   \
+            const int t2 = tile + step;                                             \
+            sb = (grp ? (t2 / p.tiles_n) * BMM : (t2 % p.tiles_n) * BNN) * p.K * 2; \
+            ISSUE2(sb, 0, 0);                                                       \
+            if (nt > 1) ISSUE2(sb, 1, 1);                                           \
+        }
+#define EPILOGUE()                                                                  \
+        {                                                                           \
+            const int sbase = ((m0 + wm * 64) * p.N + n0 + wn * 96) * 4;            \
+            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                      \
+                const int so = sbase + mi * 16 * p.N * 4;                           \
+                _Pragma("unroll") for (int ni = 0; ni < 6; ++ni)                    \
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[ni][mi]), rC, cvoff + ni * 64, so, 0); \
+            }                                                                       \
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (grp == 0) {
+            ZERO_ACC()
             for (int i = 0; i < nt; ++i) {
                 const char* st = smem + (i & 1) * STAGE;
                 READ_FRAGS(st);
@@ -153,7 +172,10 @@ __global__ void __launch_bounds__(512, 2) lab2_kernel(P p, int ntiles) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();  // end B2_i
             }
+            NEXT_ISSUE()
+            EPILOGUE()
         } else {
+            ZERO_ACC()
             for (int i = 0; i < nt; ++i) {
                 if (i >= 1) {
                     __builtin_amdgcn_s_setprio(1);
@@ -176,30 +198,10 @@ __global__ void __launch_bounds__(512, 2) lab2_kernel(P p, int ntiles) {
                 }
                 __builtin_amdgcn_s_barrier();  // end B2_i
             }
-        }
-        // every wave has read its last fragments: both stage buffers are free.  Start the next tile's first two K-tiles now,
-        // under group Y's last MFMAs and under the epilogue.
-        if (tile + step < last) {
-            const int t2 = tile + step;
-            sb = (grp ? (t2 / p.tiles_n) * BMM : (t2 % p.tiles_n) * BNN) * p.K * 2;
-            ISSUE2(sb, 0, 0);
-            if (nt > 1) ISSUE2(sb, 1, 1);
-        }
-        if (grp) {
+            NEXT_ISSUE()
             MFMA_RANGE(0, 0, 6)
             MFMA_RANGE(1, 0, 6)
-        }
-        // epilogue through a buffer descriptor: ONE per-lane offset; the tile, the wave's sub-tile and mi go into the scalar
-        // offset, ni into the instruction's immediate -- nothing per-lane for the compiler to hoist out of the tile loop
-        {
-            const int sbase = ((m0 + wm * 64) * p.N + n0 + wn * 96) * 4;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int so = sbase + mi * 16 * p.N * 4;
-#pragma unroll
-                for (int ni = 0; ni < 6; ++ni)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[ni][mi]), rC, cvoff + ni * 64, so, 0);
-            }
+            EPILOGUE()
         }
         __builtin_amdgcn_sched_barrier(0);  // the next tile's accumulators must not be set up before these stores have issued
     }

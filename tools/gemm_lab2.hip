@@ -271,6 +271,8 @@ int main(int argc, char** argv) {
         size_t bad = 0;
         for (size_t i = 0; i < r0.size(); ++i) bad += memcmp(&r0[i], &r1[i], 4) != 0;
         printf("N=%4d K=%4d  persistent (256 workgroups) %7.1f us  %6.1f TF  mismatches %zu\n", N, K, t1, fl / t1 / 1e6, bad);
+        const float t0b = run<0>(p0, iters, st), t1b = run<1>(p1, iters, st), t0c = run<0>(p0, iters, st), t1c = run<1>(p1, iters, st);
+        printf("            again: one tile %7.1f  persistent %7.1f  one tile %7.1f  persistent %7.1f\n", t0b, t1b, t0c, t1c);
         fflush(stdout);
         CK(hipFree(da)); CK(hipFree(dw)); CK(hipFree(c0)); CK(hipFree(c1));
     }

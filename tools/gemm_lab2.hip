@@ -141,6 +141,16 @@ __global__ void __launch_bounds__(512, 2) lab2_kernel(P p, int ntiles) {
             ISSUE2(sb, 0, 0);                                                       \
             if (nt > 1) ISSUE2(sb, 1, 1);                                           \
         }
+#ifdef LAB_TINY_EPI  /* the rounding kernel's situation: almost nothing leaves the workgroup */
+#define EPILOGUE()                                                                  \
+        {                                                                           \
+            f32x4 t_ = acc[0][0];                                                   \
+            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                        \
+                _Pragma("unroll") for (int ni = 0; ni < 6; ++ni)                    \
+                    if (mi + ni) t_ = t_ + acc[ni][mi];                             \
+            if (lg == 0 && wn == 0) p.C[(size_t)(m0 + wm * 64 + lr) * p.tiles_n + n0 / BNN] = t_[0] + t_[1] + t_[2] + t_[3]; \
+        }
+#else
 #define EPILOGUE()                                                                  \
         {                                                                           \
             const int sbase = ((m0 + wm * 64) * p.N + n0 + wn * 96) * 4;            \
@@ -150,6 +160,7 @@ __global__ void __launch_bounds__(512, 2) lab2_kernel(P p, int ntiles) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[ni][mi]), rC, cvoff + ni * 64, so, 0); \
             }                                                                       \
         }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (grp == 0) {
@@ -244,7 +255,11 @@ static float run(const P& p, int iters, hipStream_t st) {
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 20;
     const int M = 16384;
+#ifdef LAB_TINY_EPI
+    const int shapes[4][2] = {{8064, 768}, {49920, 768}, {3072, 768}, {768, 768}};
+#else
     const int shapes[4][2] = {{3072, 768}, {2304, 768}, {768, 768}, {768, 3072}};
+#endif
     hipStream_t st;
     CK(hipStreamCreate(&st));
     for (int s = 0; s < 4; ++s) {
@@ -265,7 +280,11 @@ int main(int argc, char** argv) {
         P p1{M, N, K, N / BNN, da, dw, c1, nullptr};
         CK(hipMemset(c1, 0, (size_t)M * N * 4));
         const float t1 = run<1>(p1, iters, st);
+#ifdef LAB_TINY_EPI
+        std::vector<float> r0((size_t)M * (N / BNN)), r1((size_t)M * (N / BNN));
+#else
         std::vector<float> r0((size_t)M * N), r1((size_t)M * N);
+#endif
         CK(hipMemcpy(r0.data(), c0, r0.size() * 4, hipMemcpyDeviceToHost));
         CK(hipMemcpy(r1.data(), c1, r1.size() * 4, hipMemcpyDeviceToHost));
         size_t bad = 0;

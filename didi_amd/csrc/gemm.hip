@@ -766,6 +766,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         // lane (lr, lg) of wave (wm, wn) holds, for row wm*64 + mi*16 + lr, the columns wn*96 + 32k + 8lg + 4h + r of tile ni = 2k + h
         float best[4];
         int bidx[4];
+        // a lane walks its 24 columns in increasing order, so a strict '>' keeps the lowest index among equal maxima; tiles that
+        // lie wholly inside the vocabulary (all but the last column tile) skip the per-element bound check
+        const int nb = n0 + wn * 96 + 8 * lg;
+        const bool inside = n0 + BBN <= p.N;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             best[mi] = -INFINITY; bidx[mi] = 0x7fffffff;
@@ -773,9 +777,9 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
             for (int ni = 0; ni < 6; ++ni)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int n = n0 + wn * 96 + 32 * (ni >> 1) + 8 * lg + 4 * (ni & 1) + r;
+                    const int off = 32 * (ni >> 1) + 4 * (ni & 1) + r;
                     const float v = acc[ni][mi][r];
-                    if (n < p.N && better(v, n, best[mi], bidx[mi])) { best[mi] = v; bidx[mi] = n; }
+                    if ((inside || nb + off < p.N) && v > best[mi]) { best[mi] = v; bidx[mi] = nb + off; }
                 }
 #pragma unroll
             for (int o = 16; o <= 32; o <<= 1) {
@@ -1488,18 +1492,28 @@ __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_argmax_kernel(G
     }
 }
 
+// one wave per row: the lanes read the row's chunk results 64 at a time (coalesced), then a butterfly picks the winner
 __global__ void __launch_bounds__(256) argmax_reduce_kernel(const float2* partial, int M, int nchunks, int V, int64_t* ids64, int32_t* ids32) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = lane; c < nchunks; c += 64) {
         const float2 q = partial[(size_t)m * nchunks + c];
         const int i = __float_as_int(q.y);
         if (better(q.x, i, bv, bi)) { bv = q.x; bi = i; }
     }
-    if (bi < 0 || bi >= V) bi = 0;
-    if (ids64) ids64[m] = bi;
-    if (ids32) ids32[m] = bi;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        if (bi < 0 || bi >= V) bi = 0;
+        if (ids64) ids64[m] = bi;
+        if (ids32) ids32[m] = bi;
+    }
 }
 
 // CE variant: ids as above, nll[m] = logsumexp(logits[m, :]) - logits[m, target[m]] (+inf for a target outside [0, V))
@@ -1580,7 +1594,7 @@ static int round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const
         else if (p.f16) gemm_pp_kernel<1, true, false, true><<<grid, 512, lds, st>>>(p);
         else gemm_pp_kernel<1, false, false, true><<<grid, 512, lds, st>>>(p);
         DIDI_LAUNCH_CHECK();
-        argmax_reduce_kernel<<<cdiv(M, 256), 256, 0, st>>>(p.partial, M, p.nchunks, V, ids64, ids32);
+        argmax_reduce_kernel<<<cdiv(M, 4), 256, 0, st>>>(p.partial, M, p.nchunks, V, ids64, ids32);
         DIDI_LAUNCH_CHECK();
         return DIDI_OK;
     }
@@ -1610,7 +1624,7 @@ static int round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const
 #undef DIDI_ROUND_LAUNCH
     DIDI_LAUNCH_CHECK();
     if (ce) ce_reduce_kernel<<<cdiv(M, 256), 256, 0, st>>>(p.partial, p.partial2, M, p.nchunks, V, ids64, nll);
-    else argmax_reduce_kernel<<<cdiv(M, 256), 256, 0, st>>>(p.partial, M, p.nchunks, V, ids64, ids32);
+    else argmax_reduce_kernel<<<cdiv(M, 4), 256, 0, st>>>(p.partial, M, p.nchunks, V, ids64, ids32);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

@@ -358,12 +358,16 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
 // the same for 8 consecutive output columns: 16-byte plane stores / loads instead of 8-byte ones (the
 // epilogue is store-issue bound: half the instructions, twice the contiguous bytes per row)
 // `pre` != 0: the residual planes of these 8 columns were loaded ahead by the caller (rh_pre, rl_pre)
+// `bias8`: this tile's bias values for columns n..n+7, staged in LDS by the kernel's prologue (null: read p.bias from memory --
+// a dependent global load at the head of the epilogue cost the qkv launch 5 us per round, tools/epi_cost.py)
 __device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32x4 lo4, f32x4 hi4, const float2* gelu_tbl,
-                                          int pre = 0, uint4 rh_pre = uint4{0, 0, 0, 0}, uint4 rl_pre = uint4{0, 0, 0, 0}) {
+                                          int pre = 0, uint4 rh_pre = uint4{0, 0, 0, 0}, uint4 rl_pre = uint4{0, 0, 0, 0},
+                                          const float* bias8 = nullptr) {
     float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     if (p.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
-        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        const float* bsrc = bias8 ? bias8 : p.bias + n;
+        const float4 b0 = *reinterpret_cast<const float4*>(bsrc);
+        const float4 b1 = *reinterpret_cast<const float4*>(bsrc + 4);
         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
         v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
     }
@@ -466,6 +470,8 @@ __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_kernel(GemmPara
 //   (T14), both stages in flight (early stage release), MT = 2, a touch-ahead L2 prefetch and
 //   padded leading dimensions were all within +-4 % of this form or slower, so it stays.
 #define BBN 192
+// dynamic LDS of gemm_pp_kernel: two stages, the 8-KiB GELU table, the tile's 192 bias values
+#define PP_LDS_BYTES (2 * BigGeom<4>::STAGE + 8192 + 1024)
 template <int MT> struct BigGeom {
     static constexpr int BM_ = MT * 64, WAVES = MT * 2, THREADS = WAVES * 64;
     static constexpr int A_BYTES = MT * 64 * 128;       // A region: [BM][128 B], or hi+lo tiles of [BM][64 B]
@@ -706,6 +712,11 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     // issued first so that every later counted wait covers it
     const bool use_lut = NPASS == 1 && p.act == DIDI_ACT_GELU;
     if (use_lut) glds16(reinterpret_cast<const u16*>(didi_gelu_table) + wave * 512 + lane * 8, smem + 2 * STAGE + wave * 1024);
+    // the tile's 192 bias values ride along too (one 768-byte piece, wave 0): the epilogue then reads them from LDS instead of
+    // opening with a dependent global load
+    float* bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE + 8192);
+    if (!AMAX && p.bias && wave == 0 && lane < 48 && n0 + 4 * lane < p.N)
+        glds16(reinterpret_cast<const u16*>(p.bias + n0 + 4 * lane), reinterpret_cast<char*>(bias_lds));
     // tile 0 must have landed before the first read; tile 1 stays in flight (first waits: end of B2_0)
     if (grp == 0) {
         PP_ISSUE(0, 0, 6);
@@ -838,7 +849,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const int n = n0 + wn * 96 + 32 * k + 8 * lg;
-                    if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi], gelu_tbl, pre, rh[mj][k], rl[mj][k]);
+                    if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi], gelu_tbl, pre, rh[mj][k], rl[mj][k], bias_lds + (n - n0));
                     else if (n < p.N) epilogue4(p, m, n, acc[2 * k][mi][0], acc[2 * k][mi][1], acc[2 * k][mi][2], acc[2 * k][mi][3]);
                 }
             }
@@ -871,7 +882,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const int n = n0 + wn * 96 + 32 * k + 8 * lg;
-                    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + (n - n0)), b1 = *reinterpret_cast<const float4*>(bias_lds + (n - n0) + 4);
                     const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
                     float rH[8], rL[8];
                     unpack4(make_uint2(rh[mj][k].x, rh[mj][k].y), rH, p.f16);
@@ -1043,7 +1054,7 @@ static bool opt_in_lds() {
 template <int NPASS, bool F16>
 static bool opt_in_lds_pp() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<NPASS, F16, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess;
+                               hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess;
 }
 // experiment knob: DIDI_GEMM_PP=0 selects the in-phase K-loop (gemm_big_kernel) for A/B timing
 static bool gemm_pp_enabled() {
@@ -1100,7 +1111,7 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
         if (mt4 && wide_ok && gemm_pp_enabled()) {
             p.tiles_m = cdiv(p.M, 256);
             const int grid = p.tiles_m * p.tiles_n;
-            const size_t lds = 2 * BigGeom<4>::STAGE + 8192;  // + GELU table
+            const size_t lds = PP_LDS_BYTES;  // + GELU table
             if (mode == 3) gemm_pp_kernel<3, false, false><<<grid, 512, lds, st>>>(p);
             else if (p.f16) gemm_pp_kernel<1, true, false><<<grid, 512, lds, st>>>(p);
             else gemm_pp_kernel<1, false, false><<<grid, 512, lds, st>>>(p);
@@ -1331,9 +1342,9 @@ extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const f
     int rc = fill_operands(p, a->precision, a->A_hi, a->A_lo, a->W_hi, a->W_lo);
     if (rc != DIDI_OK) return rc;
     if (!allow_big_lds()) return DIDI_ERR_LAUNCH;
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess &&
-                           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess &&
-                           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess;
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess &&
+                           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess &&
+                           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess;
     if (!ok) return DIDI_ERR_LAUNCH;
     p.lda = a->lda; p.ldw = a->ldw; p.bias = a->bias; p.act = DIDI_ACT_NONE; p.ldr = a->ldr; p.ldc = a->N;
     p.ln_gamma = gamma; p.ln_beta = beta; p.ln_eps = eps; p.tiles_n = 4;
@@ -1346,7 +1357,7 @@ extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const f
     p.ln_epoch = epoch;
     // row chunks of at most (CUs / 4) bands: every workgroup of a launch is resident, so band mates never wait for a CU
     const int bands_per_launch = ncu / 4;
-    const size_t lds = 2 * BigGeom<4>::STAGE + 8192;
+    const size_t lds = PP_LDS_BYTES;
     for (int b0 = 0; b0 < bands; b0 += bands_per_launch) {
         const int nb = std::min(bands_per_launch, bands - b0);
         const size_t r0 = (size_t)b0 * 256;
@@ -1582,14 +1593,14 @@ static int round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const
     if (!ce && M >= 2048 && K >= 128 && pick_mode(p) != 0 && gemm_pp_enabled() && gemm_big_enabled()) {
         // large batches: the 256x192 staggered loop with the argmax epilogue, one workgroup per (row band, 192 vocabulary columns)
         static const bool ok = allow_big_lds() &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<3, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<4>::STAGE + 8192) == hipSuccess;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<3, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess;
         if (!ok) return DIDI_ERR_LAUNCH;
         p.tiles_m = cdiv(M, 256); p.tiles_n = cdiv(V, BBN); p.nchunks = p.tiles_n;
         p.partial = reinterpret_cast<float2*>(partial);
         const int grid = p.tiles_m * p.tiles_n;
-        const size_t lds = 2 * BigGeom<4>::STAGE + 8192;
+        const size_t lds = PP_LDS_BYTES;
         if (p.npass == 3) gemm_pp_kernel<3, false, false, true><<<grid, 512, lds, st>>>(p);
         else if (p.f16) gemm_pp_kernel<1, true, false, true><<<grid, 512, lds, st>>>(p);
         else gemm_pp_kernel<1, false, false, true><<<grid, 512, lds, st>>>(p);

@@ -470,8 +470,8 @@ __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_kernel(GemmPara
 //   (T14), both stages in flight (early stage release), MT = 2, a touch-ahead L2 prefetch and
 //   padded leading dimensions were all within +-4 % of this form or slower, so it stays.
 #define BBN 192
-// dynamic LDS of gemm_pp_kernel: two stages, the 8-KiB GELU table, the tile's 192 bias values
-#define PP_LDS_BYTES (2 * BigGeom<4>::STAGE + 8192 + 1024)
+// dynamic LDS of gemm_pp_kernel: two stages, the 8-KiB GELU table, the tile's 192 bias (+ LayerNorm gamma, beta) values
+#define PP_LDS_BYTES (2 * BigGeom<4>::STAGE + 8192 + 3072)
 template <int MT> struct BigGeom {
     static constexpr int BM_ = MT * 64, WAVES = MT * 2, THREADS = WAVES * 64;
     static constexpr int A_BYTES = MT * 64 * 128;       // A region: [BM][128 B], or hi+lo tiles of [BM][64 B]
@@ -717,6 +717,12 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     float* bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE + 8192);
     if (!AMAX && p.bias && wave == 0 && lane < 48 && n0 + 4 * lane < p.N)
         glds16(reinterpret_cast<const u16*>(p.bias + n0 + 4 * lane), reinterpret_cast<char*>(bias_lds));
+    float* gamma_lds = bias_lds + 256;  // LayerNorm variant: gamma and beta of the tile's columns, waves 1 and 2
+    float* beta_lds = bias_lds + 512;
+    if constexpr (LN) {
+        if (wave == 1 && lane < 48) glds16(reinterpret_cast<const u16*>(p.ln_gamma + n0 + 4 * lane), reinterpret_cast<char*>(gamma_lds));
+        if (wave == 2 && lane < 48) glds16(reinterpret_cast<const u16*>(p.ln_beta + n0 + 4 * lane), reinterpret_cast<char*>(beta_lds));
+    }
     // tile 0 must have landed before the first read; tile 1 stays in flight (first waits: end of B2_0)
     if (grp == 0) {
         PP_ISSUE(0, 0, 6);
@@ -982,8 +988,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int n = n0 + wn * 96 + 32 * k + 8 * lg;
-            const float4 g0 = *reinterpret_cast<const float4*>(p.ln_gamma + n), g1 = *reinterpret_cast<const float4*>(p.ln_gamma + n + 4);
-            const float4 c0 = *reinterpret_cast<const float4*>(p.ln_beta + n), c1 = *reinterpret_cast<const float4*>(p.ln_beta + n + 4);
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma_lds + (n - n0)), g1 = *reinterpret_cast<const float4*>(gamma_lds + (n - n0) + 4);
+            const float4 c0 = *reinterpret_cast<const float4*>(beta_lds + (n - n0)), c1 = *reinterpret_cast<const float4*>(beta_lds + (n - n0) + 4);
             const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll

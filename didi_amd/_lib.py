@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  -- first: its bundled libamdhip64.so.7 must be the one HIP runtime in the process
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdidi_hip.so")
+LIB_PATH = os.environ.get("DIDI_HIP_LIB") or os.path.join(_HERE, "libdidi_hip.so")  # DIDI_HIP_LIB: A/B runs against another build
 
 u16p = C.POINTER(C.c_uint16)
 f32p = C.POINTER(C.c_float)

@@ -22,6 +22,11 @@ PREC_BF16, PREC_FP16, PREC_BF16X3 = 1, 2, 3
 FMT_BF16, FMT_FP16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_TANH, ACT_RELU, ACT_GELU_NEW = 0, 1, 2, 3, 4
 STEP_NONE, STEP_INIT, STEP_DDPM, STEP_EULER = 0, 1, 2, 3
+ERR_FAULT = -5
+FAULT_LN_EXCHANGE, FAULT_FP16_RANGE = 1, 2
+ABI_VERSION = 4
+# didi_set_option keys (tuning switches for A/B runs; defaults = production path)
+OPTIONS = {"GEMM_LN": 0, "GEMM_SMALL": 1, "GEMM_BIG": 2, "GEMM_PP": 3, "GEMM_MT": 4, "BIG_MIN_M": 5, "SMALL_MAX_M": 6}
 
 
 class StepArgs(C.Structure):
@@ -45,6 +50,7 @@ class GemmArgs(C.Structure):
         ("bias", C.c_void_p), ("act", C.c_int),
         ("R_f32", C.c_void_p), ("R_hi", C.c_void_p), ("R_lo", C.c_void_p), ("ldr", C.c_int),
         ("C_f32", C.c_void_p), ("C_hi", C.c_void_p), ("C_lo", C.c_void_p), ("ldc", C.c_int),
+        ("fault", C.c_void_p),
     ]
 
 
@@ -88,6 +94,7 @@ class ForwardArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("x0_f32", C.c_void_p), ("x0_hi", C.c_void_p), ("x0_lo", C.c_void_p),
         ("prof_events_host", C.POINTER(C.c_void_p)), ("prof_capacity", C.c_int), ("prof_used_host", C.POINTER(C.c_int)),
+        ("fault", C.c_void_p),
     ]
 
 
@@ -102,7 +109,7 @@ class SampleArgs(C.Structure):
         ("cls_hi", C.c_void_p), ("cls_lo", C.c_void_p), ("V", C.c_int), ("argmax_partial", C.c_void_p),
         ("ids64", C.c_void_p),
         ("prof_call", C.c_int), ("prof_events_host", C.POINTER(C.c_void_p)), ("prof_capacity", C.c_int),
-        ("prof_used_host", C.POINTER(C.c_int)), ("clamp_emb", C.c_void_p),
+        ("prof_used_host", C.POINTER(C.c_int)), ("clamp_emb", C.c_void_p), ("fault", C.c_void_p),
     ]
 
 
@@ -110,6 +117,10 @@ class SampleArgs(C.Structure):
 SYMBOLS = [
     ("didi_version", C.c_int, []),
     ("didi_error_string", C.c_char_p, [C.c_int]),
+    ("didi_fault_read", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
+    ("didi_fault_string", C.c_char_p, [C.c_uint32]),
+    ("didi_set_option", C.c_int, [C.c_int, C.c_int]),
+    ("didi_get_option", C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     ("didi_split_bf16", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("didi_split_fp16", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("didi_philox_normal", C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]),
@@ -161,8 +172,13 @@ def _load():
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.didi_version() != 3:
-        raise ImportError(f"libdidi_hip ABI version {lib.didi_version()} != 3")
+    if lib.didi_version() != ABI_VERSION:
+        raise ImportError(f"libdidi_hip ABI version {lib.didi_version()} != {ABI_VERSION}")
+    # the library never reads the environment; the tools' DIDI_<OPTION>=<int> variables are applied here, through the ABI
+    for name, key in OPTIONS.items():
+        v = os.environ.get("DIDI_" + name)
+        if v is not None and lib.didi_set_option(key, int(v)) != OK:
+            raise ImportError(f"DIDI_{name}={v}: rejected by didi_set_option")
     return lib
 
 
@@ -172,6 +188,25 @@ lib = _load()
 def check(rc, what=""):
     if rc != OK:
         raise DidiHipError(f"{what}: {lib.didi_error_string(rc).decode()} ({rc})")
+
+
+def set_option(name, value):
+    check(lib.didi_set_option(OPTIONS[name], int(value)), f"set_option {name}")
+
+
+def get_option(name):
+    v = C.c_int()
+    check(lib.didi_get_option(OPTIONS[name], C.byref(v)), f"get_option {name}")
+    return v.value
+
+
+def check_fault(fault, what=""):
+    """Wait for the current stream and raise if the device fault word (uint32 tensor of one element) is set."""
+    bits = C.c_uint32()
+    rc = lib.didi_fault_read(fault.data_ptr(), C.byref(bits), current_stream())
+    if rc == ERR_FAULT:
+        raise DidiHipError(f"{what}: device fault 0x{bits.value:x}: {lib.didi_fault_string(bits.value).decode()}")
+    check(rc, what)
 
 
 def ptr(t):

@@ -318,11 +318,10 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
     p.SP = (a->Sq + 15) / 16 * 16;
     p.CP = (a->Sk + 31) / 32 * 32;
     const size_t lds = attn_lds_bytes(DP, x3 ? 2 : 1, p.CP);  // <= 48.4 KiB: 3-4 workgroups per CU
-    // experiment knob DIDI_ATTN_NH=2|3: heads per workgroup.  Measured at B=256, 12 heads, S=64 (tools/attn_bench.py):
-    // one head 19.2 / 20.9 us (fp16 self / cross), two heads 23.8 / 24.3, three 24.2 / 24.0 -- the kernel is bound by
-    // its per-wave dependency chains, so 8 waves per SIMD beat prefetching with 4; the default stays 1.
-    static const int nh_env = [] { const char* e = getenv("DIDI_ATTN_NH"); return e ? atoi(e) : 1; }();
-    p.nh = (nh_env == 3 && a->heads % 3 == 0) ? 3 : (nh_env >= 2 && a->heads % 2 == 0 ? 2 : 1);
+    // heads per workgroup (the MULTI form of the kernel).  Measured at B=256, 12 heads, S=64 (tools/attn_bench.py): one head
+    // 19.2 / 20.9 us (fp16 self / cross), two heads 23.8 / 24.3, three 24.2 / 24.0 -- the kernel is bound by its per-wave
+    // dependency chains, so 8 waves per SIMD beat prefetching with 4: one head per workgroup it is.
+    p.nh = 1;
     dim3 grid(a->heads / p.nh, a->B);
     hipStream_t st = as_stream(stream);
     const bool nj3 = p.CP * (DP / 8) > 512;

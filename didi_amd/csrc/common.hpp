@@ -31,8 +31,18 @@ __device__ __forceinline__ float bf16_to_f32(u16 b) { return __builtin_bit_cast(
 __device__ __forceinline__ u16 f16_bits(float x) { return __builtin_bit_cast(u16, (_Float16)x); }
 __device__ __forceinline__ float f16_to_f32(u16 b) { return (float)__builtin_bit_cast(_Float16, b); }
 
-__device__ __forceinline__ void split2(float x, u16& hi, u16& lo, int f16 = 0) {
+// fp16 planes saturate instead of overflowing: |x| > 65504 is stored as +-65504 (a NaN stays a NaN), so one outlier
+// feature cannot turn a row into inf -> NaN in the next LayerNorm.  GEMM epilogues also report it (DIDI_FAULT_FP16_RANGE).
+#define DIDI_F16_MAX 65504.0f
+__device__ __forceinline__ float sat_f16(float x) { return fabsf(x) > DIDI_F16_MAX ? copysignf(DIDI_F16_MAX, x) : x; }
+__device__ __forceinline__ bool over_f16(float x) { return fabsf(x) > DIDI_F16_MAX; }
+
+// `sat`: callers whose values are not bounded by construction (GEMM epilogues, fp32 -> plane splits) pass true; softmax
+// probabilities, attention outputs (convex combinations of saturated V rows) and LayerNorm outputs (|y| <= sqrt(H) |gamma| + |beta|)
+// skip the three extra VALU instructions per value.
+__device__ __forceinline__ void split2(float x, u16& hi, u16& lo, int f16 = 0, bool sat = false) {
     if (f16) {
+        if (sat) x = sat_f16(x);
         hi = f16_bits(x);
         lo = f16_bits(x - f16_to_f32(hi));
     } else {
@@ -45,18 +55,18 @@ __device__ __forceinline__ float join2(u16 hi, u16 lo, int f16 = 0) {
 }
 
 // 4 consecutive values -> two 8-byte packs (hi plane, lo plane)
-__device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo, int f16 = 0) {
+__device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo, int f16 = 0, bool sat = false) {
     u16 h[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split2(v[i], h[i], l[i], f16);
+    for (int i = 0; i < 4; ++i) split2(v[i], h[i], l[i], f16, sat);
     hi = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
     lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
 // hi plane only (callers that do not keep the remainder)
-__device__ __forceinline__ uint2 pack4_hi(const float v[4], int f16 = 0) {
+__device__ __forceinline__ uint2 pack4_hi(const float v[4], int f16 = 0, bool sat = false) {
     u16 h[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) h[i] = f16 ? f16_bits(v[i]) : bf16_bits(v[i]);
+    for (int i = 0; i < 4; ++i) h[i] = f16 ? f16_bits(sat ? sat_f16(v[i]) : v[i]) : bf16_bits(v[i]);
     return make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
 }
 __device__ __forceinline__ void unpack4(uint2 p, float v[4], int f16 = 0) {
@@ -79,6 +89,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// raises `bit` in the device fault word: one atomic per wave that saw the condition (rare: normally none)
+__device__ __forceinline__ void raise_fault(uint32_t* fault, bool cond, uint32_t bit) {
+    if (fault && cond) {  // the first active lane that saw it writes
+        const unsigned long long act = __ballot(1);
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicOr(fault, bit);
+    }
+}
+
+// classifier GEMM + argmax (+ cross-entropy terms when targets != null) with caller-provided partials: gemm.hip
+int didi_round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uint16_t* W_hi, const uint16_t* W_lo, int ldw,
+                    int M, int V, int K, int precision, void* partial, int64_t* ids64, int32_t* ids32, const int64_t* targets,
+                    float* nll, void* stream);
+
+// process-wide tuning switches (didi_set_option; engine.hip holds the table)
+int didi_opt(int key);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

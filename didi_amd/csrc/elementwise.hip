@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) split_kernel(const float* src, u16* hi, u
         const float4 v = reinterpret_cast<const float4*>(src)[i];
         const float f[4] = {v.x, v.y, v.z, v.w};
         uint2 h, l;
-        split4(f, h, l, f16);
+        split4(f, h, l, f16, true);
         reinterpret_cast<uint2*>(hi)[i] = h;
         if (lo) reinterpret_cast<uint2*>(lo)[i] = l;
     }
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256) mul_split_kernel(const float* a, const fl
     const float4 u = reinterpret_cast<const float4*>(a)[i], w = reinterpret_cast<const float4*>(b)[i];
     const float y[4] = {u.x * w.x, u.y * w.y, u.z * w.z, u.w * w.w};
     uint2 h, l;
-    split4(y, h, l, f16);
+    split4(y, h, l, f16, true);
     reinterpret_cast<uint2*>(y_hi)[i] = h;
     if (y_lo) reinterpret_cast<uint2*>(y_lo)[i] = l;
 }
@@ -398,6 +398,29 @@ extern "C" const char* didi_error_string(int code) {
         case DIDI_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
         case DIDI_ERR_LAUNCH: return "kernel launch failed";
         case DIDI_ERR_WORKSPACE: return "workspace too small";
+        case DIDI_ERR_FAULT: return "device-side fault word is set (didi_fault_string names the bits)";
         default: return "unknown error";
     }
+}
+
+extern "C" const char* didi_fault_string(uint32_t bits) {
+    switch (bits & (DIDI_FAULT_LN_EXCHANGE | DIDI_FAULT_FP16_RANGE)) {
+        case 0: return bits ? "unknown fault bits" : "no fault";
+        case DIDI_FAULT_LN_EXCHANGE:
+            return "LayerNorm row-statistics exchange timed out (didi_gemm_ln launch not co-resident): rows are NaN";
+        case DIDI_FAULT_FP16_RANGE:
+            return "a GEMM output exceeded the fp16 range and was saturated to +-65504: use precision bf16x3";
+        default:
+            return "LayerNorm row-statistics exchange timed out AND a GEMM output exceeded the fp16 range";
+    }
+}
+
+// host-side helper; the one call that waits for the stream
+extern "C" int didi_fault_read(const uint32_t* fault, uint32_t* bits_host, void* stream) {
+    DIDI_CHECK_ARG(fault);
+    uint32_t bits = 0;
+    if (hipMemcpyAsync(&bits, fault, sizeof(bits), hipMemcpyDeviceToHost, as_stream(stream)) != hipSuccess) return DIDI_ERR_LAUNCH;
+    if (hipStreamSynchronize(as_stream(stream)) != hipSuccess) return DIDI_ERR_LAUNCH;
+    if (bits_host) *bits_host = bits;
+    return bits ? DIDI_ERR_FAULT : DIDI_OK;
 }

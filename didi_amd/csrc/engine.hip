@@ -72,16 +72,14 @@ struct Prof {
     }
 };
 
-// DIDI_GEMM_SMALL=0: A/B switch from the split-K small-batch form back to the plain 128x128 launch
-bool small_enabled() {
-    static const bool v = [] { const char* e = getenv("DIDI_GEMM_SMALL"); return !(e && e[0] == '0'); }();
-    return v;
-}
+// DIDI_OPT_GEMM_SMALL = 0: A/B switch from the split-K small-batch form back to the plain 128x128 launch
+bool small_enabled() { return didi_opt(DIDI_OPT_GEMM_SMALL) != 0; }
 
 int gemm(const didi_linear& w, int precision, int M, const u16* a_hi, const u16* a_lo, int lda, int act, const u16* r_hi,
          const u16* r_lo, int ldr, float* c_f32, u16* c_hi, u16* c_lo, int ldc, void* stream, Prof* prof = nullptr,
-         void* small_ws = nullptr) {
+         void* small_ws = nullptr, uint32_t* fault = nullptr) {
     didi_gemm_args g{};
+    g.fault = fault;
     g.M = M; g.N = w.N; g.K = w.K; g.precision = precision;
     g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
     g.W_hi = w.w_hi; g.W_lo = w.w_lo; g.ldw = w.K;
@@ -99,13 +97,11 @@ int gemm(const didi_linear& w, int precision, int M, const u16* a_hi, const u16*
 // else GEMM -> fp32 tmp -> LayerNorm.  `epoch` tags this launch's statistics in the shared `stats` buffer.
 int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi, const u16* a_lo, int lda, const u16* r_hi,
             const u16* r_lo, int ldr, float* tmp, void* stats, uint32_t epoch, const float* gamma, const float* beta, float eps,
-            u16* y_hi, u16* y_lo, float* y_f32, void* stream, Prof* prof, void* small_ws) {
-    static const bool fuse = [] {  // DIDI_GEMM_LN=0: A/B switch back to GEMM + LayerNorm
-        const char* e = getenv("DIDI_GEMM_LN");
-        return !(e && e[0] == '0');
-    }();
+            u16* y_hi, u16* y_lo, float* y_f32, void* stream, Prof* prof, void* small_ws, uint32_t* fault) {
+    const bool fuse = didi_opt(DIDI_OPT_GEMM_LN) != 0;  // 0: A/B switch back to GEMM + LayerNorm
     if (fuse && didi_gemm_ln_supported(M, w.N, w.K, precision) && w.bias) {
         didi_gemm_args g{};
+        g.fault = fault;
         g.M = M; g.N = w.N; g.K = w.K; g.precision = precision;
         g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
         g.W_hi = w.w_hi; g.W_lo = w.w_lo; g.ldw = w.K;
@@ -118,6 +114,7 @@ int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi
     }
     if (small_ws && small_enabled() && didi_gemm_small_workspace_bytes(M, w.N, w.K, precision)) {  // LayerNorm rides in the row kernel
         didi_gemm_args g{};
+        g.fault = fault;
         g.M = M; g.N = w.N; g.K = w.K; g.precision = precision;
         g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
         g.W_hi = w.w_hi; g.W_lo = w.w_lo; g.ldw = w.K;
@@ -129,12 +126,29 @@ int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi
         if (prof) prof->mark(stream);
         return rc;
     }
-    int rc = gemm(w, precision, M, a_hi, a_lo, lda, DIDI_ACT_NONE, r_hi, r_lo, ldr, tmp, nullptr, nullptr, w.N, stream, prof);
+    int rc = gemm(w, precision, M, a_hi, a_lo, lda, DIDI_ACT_NONE, r_hi, r_lo, ldr, tmp, nullptr, nullptr, w.N, stream, prof, nullptr, fault);
     if (rc != DIDI_OK) return rc;
     return didi_layernorm(tmp, gamma, beta, eps, M, w.N, y_hi, y_lo, y_f32, fmt, stream);
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------ tuning switches (didi_set_option)
+static int g_options[DIDI_OPT_COUNT] = {/*GEMM_LN*/ 1, /*GEMM_SMALL*/ 1, /*GEMM_BIG*/ 1, /*GEMM_PP*/ 1, /*GEMM_MT*/ 4,
+                                        /*BIG_MIN_M*/ 2048, /*SMALL_MAX_M*/ 2048};
+int didi_opt(int key) { return g_options[key]; }
+extern "C" int didi_set_option(int key, int value) {
+    DIDI_CHECK_ARG(key >= 0 && key < DIDI_OPT_COUNT);
+    if (key == DIDI_OPT_GEMM_MT) DIDI_CHECK_ARG(value == 2 || value == 4);
+    if (key == DIDI_OPT_BIG_MIN_M || key == DIDI_OPT_SMALL_MAX_M) DIDI_CHECK_ARG(value >= 0);
+    g_options[key] = value;
+    return DIDI_OK;
+}
+extern "C" int didi_get_option(int key, int* value) {
+    DIDI_CHECK_ARG(key >= 0 && key < DIDI_OPT_COUNT && value);
+    *value = g_options[key];
+    return DIDI_OK;
+}
 
 #define TRY(x)                     \
     do {                           \
@@ -208,7 +222,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         const bool last = l == dec->L - 1;
         // --- causal self-attention block
         TRY(gemm(ly.qkv, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, w.qkv_hi,
-                 x3 ? w.qkv_lo : nullptr, 3 * H, stream, &prof, w.small_ws));
+                 x3 ? w.qkv_lo : nullptr, 3 * H, stream, &prof, w.small_ws, a->fault));
         didi_attn_args at{};
         at.B = a->B; at.heads = dec->heads; at.Sq = a->S; at.Sk = a->S; at.D = D; at.precision = prec;
         at.causal = 1; at.key_mask = nullptr;
@@ -218,11 +232,11 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.O_hi = w.att_hi; at.O_lo = x3 ? w.att_lo : nullptr; at.ldo = H;
         TRY(didi_attention(&at, stream));
         TRY(gemm_ln(ly.attn_out, prec, fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln1_g, ly.ln1_b,
-                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws));
+                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault));
         // --- cross-attention block (K/V hoisted: didi_decoder_prepare_context)
         u16* q_hi = w.qkv_hi;
         u16* q_lo = x3 ? w.qkv_lo : nullptr;
-        TRY(gemm(ly.cq, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream, &prof, w.small_ws));
+        TRY(gemm(ly.cq, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream, &prof, w.small_ws, a->fault));
         const size_t kvoff = (size_t)l * Mc * 2 * H;
         at.Sk = a->C; at.causal = 0; at.key_mask = a->ctx_mask;
         at.Q_hi = q_hi; at.Q_lo = q_lo; at.ldq = H;
@@ -230,14 +244,14 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;
         TRY(didi_attention(&at, stream));
         TRY(gemm_ln(ly.cross_out, prec, fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln2_g, ly.ln2_b,
-                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws));
+                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault));
         // --- feed-forward block
         TRY(gemm(ly.ffn_up, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_GELU, nullptr, nullptr, 0, nullptr, w.ffn_hi,
-                 x3 ? w.ffn_lo : nullptr, I, stream, &prof, w.small_ws));
+                 x3 ? w.ffn_lo : nullptr, I, stream, &prof, w.small_ws, a->fault));
         u16* o_hi = last && a->x0_hi ? a->x0_hi : w.h_hi;
         u16* o_lo = last && a->x0_hi ? a->x0_lo : w.h_lo;
         TRY(gemm_ln(ly.ffn_down, prec, fmt, M, w.ffn_hi, w.ffn_lo, I, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln3_g, ly.ln3_b,
-                    dec->ln_eps, o_hi, o_lo, last ? a->x0_f32 : nullptr, stream, &prof, w.small_ws));
+                    dec->ln_eps, o_hi, o_lo, last ? a->x0_f32 : nullptr, stream, &prof, w.small_ws, a->fault));
     }
     if (a->prof_used_host) *a->prof_used_host = prof.used;
     return DIDI_OK;
@@ -259,6 +273,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
     f.kv_hi = s->kv_hi; f.kv_lo = s->kv_lo; f.ctx_mask = s->ctx_mask;
     f.workspace = s->workspace; f.workspace_bytes = s->workspace_bytes;
     f.x0_f32 = s->x0_f32;
+    f.fault = s->fault;
     auto draw = [&](int i) -> const float* { return s->noise ? s->noise + (size_t)i * MH : nullptr; };
     // per-step clamp extension: x0 <- emb[argmax(classifier(x0))]; the forward leaves x0 planes for the rounding GEMM
     const bool clamp = s->clamp_emb != nullptr;

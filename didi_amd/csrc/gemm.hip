@@ -35,6 +35,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "common.hpp"
 
@@ -71,6 +72,7 @@ struct GemmParams {
     float ln_eps;
     unsigned long long* ln_stats;  // [tiles_m][tiles_n][256][2] granules {epoch, bits} of each tile's per-row (sum, M2)
     unsigned ln_epoch;             // tag of this launch's granules (>= 1; older tags and zero are stale)
+    uint32_t* fault;               // device fault word (DIDI_FAULT_*) or null
 };
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
@@ -348,8 +350,9 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
     if (p.C_f32) *reinterpret_cast<float4*>(p.C_f32 + o) = make_float4(v0, v1, v2, v3);
     if (p.C_hi) {
         const float v[4] = {v0, v1, v2, v3};
+        if (p.f16) raise_fault(p.fault, over_f16(v0) || over_f16(v1) || over_f16(v2) || over_f16(v3), DIDI_FAULT_FP16_RANGE);
         uint2 h, l;
-        split4(v, h, l, p.f16);
+        split4(v, h, l, p.f16, true);
         *reinterpret_cast<uint2*>(p.C_hi + o) = h;
         if (p.C_lo) *reinterpret_cast<uint2*>(p.C_lo + o) = l;
     }
@@ -403,14 +406,20 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32
         *reinterpret_cast<float4*>(p.C_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(p.C_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
     }
+    if (p.C_hi && p.f16) {
+        bool ovf = false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ovf = ovf || over_f16(v[i]);
+        raise_fault(p.fault, ovf, DIDI_FAULT_FP16_RANGE);
+    }
     if (p.C_hi && p.C_lo) {
         uint2 h0, l0, h1, l1;
-        split4(v, h0, l0, p.f16);
-        split4(v + 4, h1, l1, p.f16);
+        split4(v, h0, l0, p.f16, true);
+        split4(v + 4, h1, l1, p.f16, true);
         *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
         *reinterpret_cast<uint4*>(p.C_lo + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     } else if (p.C_hi) {  // one-product precisions keep no remainder of GEMM-only operands
-        const uint2 h0 = pack4_hi(v, p.f16), h1 = pack4_hi(v + 4, p.f16);
+        const uint2 h0 = pack4_hi(v, p.f16, true), h1 = pack4_hi(v + 4, p.f16, true);
         *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
     }
 }
@@ -982,6 +991,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
             // a sweep that gave up (a band mate never ran: the launch was not co-resident) poisons its rows, so the failure
             // shows as NaN downstream instead of as plausible numbers
             mr[tid] = complete ? make_float2(mean, 1.0f / sqrtf(M2 / n_all + p.ln_eps)) : make_float2(__builtin_nanf(""), __builtin_nanf(""));
+            raise_fault(p.fault, !complete, DIDI_FAULT_LN_EXCHANGE);
         }
         __syncthreads();
         // 7. normalise this workgroup's slice and store it
@@ -1042,37 +1052,48 @@ static int pick_mode(const GemmParams& p) {
     return p.K % 64 == 0 ? 1 : 0;
 }
 
-// experiment knob (tools/gemm_bench.py): DIDI_GEMM_BIG=0 forces the 128x128 tile everywhere
-static bool gemm_big_enabled() {
-    static const bool v = [] { const char* e = getenv("DIDI_GEMM_BIG"); return e ? atoi(e) != 0 : true; }();
-    return v;
-}
-// experiment knob: DIDI_GEMM_MT=2 selects the 128-row, 4-wave form of the big tile (default 4: measured faster)
-static int gemm_big_mt() {
-    static const int v = [] { const char* e = getenv("DIDI_GEMM_MT"); return e && atoi(e) == 2 ? 2 : 4; }();
-    return v;
-}
+// experiment knob (tools/gemm_bench.py): DIDI_OPT_GEMM_BIG = 0 forces the 128x128 tile everywhere
+static bool gemm_big_enabled() { return didi_opt(DIDI_OPT_GEMM_BIG) != 0; }
+// experiment knob: DIDI_OPT_GEMM_MT = 2 selects the 128-row, 4-wave form of the big tile (default 4: measured faster)
+static int gemm_big_mt() { return didi_opt(DIDI_OPT_GEMM_MT) == 2 ? 2 : 4; }
 template <int NPASS, int MT, bool F16>
 static bool opt_in_lds() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<NPASS, MT, F16>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BigGeom<MT>::STAGE) == hipSuccess;
 }
-template <int NPASS, bool F16>
-static bool opt_in_lds_pp() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<NPASS, F16, false>),
+// experiment knob: DIDI_OPT_GEMM_PP = 0 selects the in-phase K-loop (gemm_big_kernel) for A/B timing
+static bool gemm_pp_enabled() { return didi_opt(DIDI_OPT_GEMM_PP) != 0; }
+// Per-device set-up, done on the first call on each device: the > 64 KiB dynamic-LDS opt-ins of every big-tile kernel
+// (function attributes live per device) and the device's CU count.  Keyed by the CURRENT device, so a process that
+// drives several GPUs gets each one's own values.
+template <int NPASS, bool F16, bool LN, bool AMAX>
+static bool opt_in_pp() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<NPASS, F16, LN, AMAX>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess;
 }
-// experiment knob: DIDI_GEMM_PP=0 selects the in-phase K-loop (gemm_big_kernel) for A/B timing
-static bool gemm_pp_enabled() {
-    static const bool v = [] { const char* e = getenv("DIDI_GEMM_PP"); return e ? atoi(e) != 0 : true; }();
-    return v;
+struct DeviceInfo { int state; int ncu; };  // state: 0 = not probed, 1 = ready, -1 = failed
+static const DeviceInfo* device_info() {
+    constexpr int MAXDEV = 64;
+    static DeviceInfo info[MAXDEV];
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    DeviceInfo& d = info[dev];
+    if (d.state == 0) {
+        bool ok = opt_in_lds<3, 4, false>() && opt_in_lds<1, 4, false>() && opt_in_lds<1, 4, true>() &&
+                  opt_in_lds<3, 2, false>() && opt_in_lds<1, 2, false>() && opt_in_lds<1, 2, true>();
+        ok = ok && opt_in_pp<3, false, false, false>() && opt_in_pp<1, false, false, false>() && opt_in_pp<1, true, false, false>();
+        ok = ok && opt_in_pp<3, false, true, false>() && opt_in_pp<1, false, true, false>() && opt_in_pp<1, true, true, false>();
+        ok = ok && opt_in_pp<3, false, false, true>() && opt_in_pp<1, false, false, true>() && opt_in_pp<1, true, false, true>();
+        int c = 0;
+        ok = ok && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0;
+        d.ncu = c;
+        d.state = ok ? 1 : -1;
+    }
+    return d.state == 1 ? &d : nullptr;
 }
-static bool allow_big_lds() {  // > 64 KiB of dynamic LDS needs an opt-in, once per process
-    static const bool ok = opt_in_lds_pp<3, false>() && opt_in_lds_pp<1, false>() && opt_in_lds_pp<1, true>() &&
-                           opt_in_lds<3, 4, false>() && opt_in_lds<1, 4, false>() && opt_in_lds<1, 4, true>() &&
-                           opt_in_lds<3, 2, false>() && opt_in_lds<1, 2, false>() && opt_in_lds<1, 2, true>();
-    return ok;
-}
+static bool allow_big_lds() { return device_info() != nullptr; }
 template <int NPASS, int MT, bool F16>
 static void launch_big(GemmParams& p, hipStream_t st) {
     using G = BigGeom<MT>;
@@ -1102,10 +1123,11 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
     p.bias = a->bias; p.act = a->act;
     p.R_f32 = a->R_f32; p.R_hi = a->R_hi; p.R_lo = a->R_lo; p.ldr = a->ldr;
     p.C_f32 = a->C_f32; p.C_hi = a->C_hi; p.C_lo = a->C_lo; p.ldc = a->ldc;
+    p.fault = a->fault;
     hipStream_t st = as_stream(stream);
     const int mode = pick_mode(p);
     const int big_tiles_n = cdiv(a->N, BBN);
-    static const int big_min_m = [] { const char* e = getenv("DIDI_BIG_MIN_M"); return e ? atoi(e) : 2048; }();  // tuning knob
+    const int big_min_m = didi_opt(DIDI_OPT_BIG_MIN_M);  // tuning knob
     const bool big = mode != 0 && gemm_big_enabled() && a->M >= big_min_m && a->N >= BBN &&
                      (long)big_tiles_n * BBN * 100 <= (long)a->N * 115;  // <= 15 % padded columns
     if (big) {
@@ -1146,7 +1168,7 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
 // raw partial sums go to a workspace (L2-resident: <= 64 KiB per workgroup), and ONE row kernel adds them up and applies
 // bias, activation, residual and, for the output projections, LayerNorm -- so the separate LayerNorm pass goes away too.
 static int small_splits(int M, int N, int K, int precision) {
-    static const int max_m = [] { const char* e = getenv("DIDI_SMALL_MAX_M"); return e ? atoi(e) : 2048; }();  // tuning knob
+    const int max_m = didi_opt(DIDI_OPT_SMALL_MAX_M);  // tuning knob
     if (M <= 0 || M >= max_m || N % 4 != 0 || N > 3072) return 0;
     const int unit = 128;  // K columns per split are a multiple of this (two one-product K-tiles, four bf16x3 ones)
     if (K % unit != 0 || K < 2 * unit) return 0;
@@ -1172,6 +1194,7 @@ struct RowsParams {
     const u16 *r_hi, *r_lo; const float* r_f32; int ldr;
     const float *gamma, *beta; float eps;
     u16 *y_hi, *y_lo; float* y_f32; int f16;
+    uint32_t* fault;
 };
 
 __device__ __forceinline__ float4 rows_value(const RowsParams& p, int m, int c) {
@@ -1214,8 +1237,9 @@ __device__ __forceinline__ void rows_store(const RowsParams& p, int m, int c, co
     const size_t o = (size_t)m * p.N + (size_t)c * 4;
     if (p.y_f32) *reinterpret_cast<float4*>(p.y_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
     if (p.y_hi) {
+        if (p.f16) raise_fault(p.fault, over_f16(y[0]) || over_f16(y[1]) || over_f16(y[2]) || over_f16(y[3]), DIDI_FAULT_FP16_RANGE);
         uint2 h, l;
-        split4(y, h, l, p.f16);
+        split4(y, h, l, p.f16, true);
         *reinterpret_cast<uint2*>(p.y_hi + o) = h;
         if (p.y_lo) *reinterpret_cast<uint2*>(p.y_lo + o) = l;
     }
@@ -1307,6 +1331,7 @@ extern "C" int didi_gemm_small(const didi_gemm_args* a, const float* gamma, cons
     r.r_hi = a->R_hi; r.r_lo = a->R_lo; r.r_f32 = a->R_f32; r.ldr = a->ldr;
     r.gamma = gamma; r.beta = beta; r.eps = eps;
     r.y_hi = a->C_hi; r.y_lo = a->C_lo; r.y_f32 = a->C_f32; r.f16 = a->precision == DIDI_PREC_FP16;
+    r.fault = a->fault;
     if (!gamma) splitk_sum_kernel<<<cdiv((long)a->M * (a->N / 4), 256), 256, 0, st>>>(r);
     else if (a->N <= 1024) splitk_ln_kernel<1><<<a->M, 256, 0, st>>>(r);
     else if (a->N <= 2048) splitk_ln_kernel<2><<<a->M, 256, 0, st>>>(r);
@@ -1316,15 +1341,6 @@ extern "C" int didi_gemm_small(const didi_gemm_args* a, const float* gamma, cons
 }
 
 // ------------------------------------------------------------------ output projection + residual + LayerNorm
-static int ln_cus() {  // workgroups that are certainly co-resident: one per CU (the kernel takes 120 KiB of LDS)
-    static const int n = [] {
-        int dev = 0, c = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 0;
-        return c;
-    }();
-    return n;
-}
-
 extern "C" int didi_gemm_ln_supported(int M, int N, int K, int precision) {
     const bool prec_ok = precision == DIDI_PREC_BF16 || precision == DIDI_PREC_FP16 || precision == DIDI_PREC_BF16X3;
     return prec_ok && M >= 2048 && N == 4 * BBN && K % 64 == 0 && K >= 128;
@@ -1341,19 +1357,15 @@ extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const f
     DIDI_CHECK_ARG(al16(a->A_hi) && al16(a->A_lo) && al16(a->W_hi) && al16(a->W_lo) && al16(a->bias) && al16(a->R_hi) && al16(a->R_lo));
     DIDI_CHECK_ARG(al16(gamma) && al16(beta) && al16(y_hi) && al16(y_lo) && al16(y_f32) && al16(stats));
     if (a->M == 0) return DIDI_OK;
-    const int ncu = ln_cus();
-    if (ncu < 4) return DIDI_ERR_LAUNCH;
+    const DeviceInfo* di = device_info();  // of the current device: opt-ins done, CU count known
+    if (!di || di->ncu < 4) return DIDI_ERR_LAUNCH;
+    const int ncu = di->ncu;
     GemmParams p{};
     p.N = a->N; p.K = a->K;
     int rc = fill_operands(p, a->precision, a->A_hi, a->A_lo, a->W_hi, a->W_lo);
     if (rc != DIDI_OK) return rc;
-    if (!allow_big_lds()) return DIDI_ERR_LAUNCH;
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess &&
-                           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess &&
-                           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess;
-    if (!ok) return DIDI_ERR_LAUNCH;
     p.lda = a->lda; p.ldw = a->ldw; p.bias = a->bias; p.act = DIDI_ACT_NONE; p.ldr = a->ldr; p.ldc = a->N;
-    p.ln_gamma = gamma; p.ln_beta = beta; p.ln_eps = eps; p.tiles_n = 4;
+    p.ln_gamma = gamma; p.ln_beta = beta; p.ln_eps = eps; p.tiles_n = 4; p.fault = a->fault;
     hipStream_t st = as_stream(stream);
     const int bands = cdiv(a->M, 256);
     if (epoch == 0) {  // stand-alone use: clear the granules, then tag 1
@@ -1563,9 +1575,7 @@ extern "C" size_t didi_round_argmax_bytes(int M, int V) {
 
 extern "C" size_t didi_round_ce_bytes(int M, int V) { return 2 * didi_round_argmax_bytes(M, V); }
 
-static int round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uint16_t* W_hi, const uint16_t* W_lo, int ldw,
-                      int M, int V, int K, int precision, void* partial, int64_t* ids64, int32_t* ids32, const int64_t* targets,
-                      float* nll, void* stream);
+#define round_impl didi_round_impl  // shared with round_static.hip (declared in common.hpp)
 
 extern "C" int didi_round_argmax(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uint16_t* W_hi,
                                  const uint16_t* W_lo, int ldw, int M, int V, int K, int precision, void* partial,
@@ -1581,9 +1591,9 @@ extern "C" int didi_round_ce(const uint16_t* X_hi, const uint16_t* X_lo, int ldx
     return round_impl(X_hi, X_lo, ldx, W_hi, W_lo, ldw, M, V, K, precision, partial, ids64, nullptr, targets, nll, stream);
 }
 
-static int round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uint16_t* W_hi, const uint16_t* W_lo, int ldw,
-                      int M, int V, int K, int precision, void* partial, int64_t* ids64, int32_t* ids32, const int64_t* targets,
-                      float* nll, void* stream) {
+int didi_round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uint16_t* W_hi, const uint16_t* W_lo, int ldw,
+                    int M, int V, int K, int precision, void* partial, int64_t* ids64, int32_t* ids32, const int64_t* targets,
+                    float* nll, void* stream) {
     const bool ce = targets != nullptr;
     DIDI_CHECK_ARG(X_hi && W_hi && partial && M >= 0 && V > 0 && K > 0);
     if (K % 8 != 0) return DIDI_ERR_UNSUPPORTED;
@@ -1598,11 +1608,7 @@ static int round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const
     hipStream_t st = as_stream(stream);
     if (!ce && M >= 2048 && K >= 128 && pick_mode(p) != 0 && gemm_pp_enabled() && gemm_big_enabled()) {
         // large batches: the 256x192 staggered loop with the argmax epilogue, one workgroup per (row band, 192 vocabulary columns)
-        static const bool ok = allow_big_lds() &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<3, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<1, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess;
-        if (!ok) return DIDI_ERR_LAUNCH;
+        if (!allow_big_lds()) return DIDI_ERR_LAUNCH;
         p.tiles_m = cdiv(M, 256); p.tiles_n = cdiv(V, BBN); p.nchunks = p.tiles_n;
         p.partial = reinterpret_cast<float2*>(partial);
         const int grid = p.tiles_m * p.tiles_n;

@@ -68,19 +68,39 @@ def gather_ids(ids: torch.Tensor, lengths: torch.Tensor, batch: int, world: int)
     return out[:, :S].to(torch.int64), out[:, S].contiguous()
 
 
-def sample_sharded(raw_context, model, mode, step_freq, *, rank, world, noise_factor=1, max_len=-1, eos_id=None, **kw):
-    """Every rank passes the SAME global batch; each samples its shard and all ranks get all ids."""
-    from .sampling import sample
+def sample_sharded(raw_context, model, mode, step_freq, *, rank, world, noise_factor=1, max_len=-1, eos_id=None,
+                   global_batch=None, sample_fn=None, **kw):
+    """Sample this rank's shard and all-gather the ids: every rank returns (ids [B, S], lengths [B]) of the WHOLE batch.
+
+    ``raw_context`` is the global batch (every rank passes the same tensors; the rank's rows are sliced out here) or, with
+    ``global_batch=B``, only this rank's shard -- rows ``shard_bounds(B, world, rank)`` of the global batch -- so that a rank
+    never uploads dialogs it does not sample (bench.py).  A rank whose shard is empty (B < world) samples nothing and
+    contributes no rows.  ``sample_fn`` replaces ``didi_amd.sampling.sample`` (the CPU gloo tests pass a stub).
+    """
     from .synthetic import RawContext
 
-    B = raw_context.input_ids.shape[0]
-    a, b = shard_bounds(B, world, rank)
-    local = RawContext(raw_context.input_ids[a:b].contiguous(), raw_context.attention_mask[a:b].contiguous())
+    if sample_fn is None:
+        from .sampling import sample as sample_fn
+    if global_batch is None:
+        B = raw_context.input_ids.shape[0]
+        a, b = shard_bounds(B, world, rank)
+        local = RawContext(raw_context.input_ids[a:b].contiguous(), raw_context.attention_mask[a:b].contiguous())
+    else:
+        B = int(global_batch)
+        a, b = shard_bounds(B, world, rank)
+        local = raw_context
+        if local.input_ids.shape[0] != b - a:
+            raise ValueError(f"rank {rank} of {world}: shard of a batch of {B} has {b - a} rows, got {local.input_ids.shape[0]}")
 
     class _Eos:
         eos_token_id, sep_token_id = eos_id, None
 
-    ids, lengths = sample(local, model, mode, step_freq, noise_factor=noise_factor, max_len=max_len,
-                          tokenizer=_Eos() if eos_id is not None else None, return_ids=True,
-                          philox_offset=philox_offset(rank), **kw)
+    if b > a:
+        ids, lengths = sample_fn(local, model, mode, step_freq, noise_factor=noise_factor, max_len=max_len,
+                                 tokenizer=_Eos() if eos_id is not None else None, return_ids=True,
+                                 philox_offset=philox_offset(rank), **kw)
+    else:  # empty shard: the reply length still has to be known for the gather
+        S = kw.get("target_len") or len(range(local.input_ids.shape[1])[:max_len])  # src/sampling.py:11
+        dev = local.input_ids.device
+        ids, lengths = torch.empty((0, S), dtype=torch.int64, device=dev), torch.empty((0,), dtype=torch.int32, device=dev)
     return gather_ids(ids, lengths, B, world)

@@ -307,6 +307,7 @@ class DiDiSampler:
                 x0_lo=torch.empty((B * S, H), dtype=self._pd, device=dev),
                 x_state=torch.empty((B, S, H), dtype=torch.float32, device=dev),
                 partial=torch.empty(lib.didi_round_argmax_bytes(B * S, self.cfg.vocab), dtype=torch.uint8, device=dev),
+                fault=ops.new_fault(dev),  # device fault word (DIDI_FAULT_*), sticky until check_fault() reads and clears it
             )
             self._bufs = {key: b}  # keep one shape resident
             self._ctx_key = None
@@ -347,10 +348,21 @@ class DiDiSampler:
         fa.kv_hi, fa.kv_lo, fa.ctx_mask = b["kv_hi"].data_ptr(), b["kv_lo"].data_ptr(), b["mask32"].data_ptr()
         fa.workspace, fa.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
         fa.x0_f32 = out.data_ptr()
+        fa.fault = b["fault"].data_ptr()
         _lib.check(lib.didi_decoder_forward(C.byref(self._dec), C.byref(fa), _lib.current_stream()), "decoder_forward")
         return out, context
 
     forward = __call__
+
+    def check_fault(self, what="didi"):
+        """Synchronise and raise DidiHipError if any kernel since the last check reported a device-side fault
+        (LayerNorm exchange timeout, fp16 range).  ``sample()`` calls it wherever it synchronises anyway; callers of
+        ``return_ids=True`` / ``model(...)`` (no host sync on those paths) call it when they want the verdict."""
+        for b in self._bufs.values():
+            try:
+                _lib.check_fault(b["fault"], what)
+            finally:
+                b["fault"].zero_()
 
     def eval(self):
         return self

@@ -77,8 +77,13 @@ def layernorm(x, gamma, beta, eps, planes=True, need_lo=True, f32=False, dtype=t
     return hi, lo, y
 
 
+def new_fault(device):
+    """A zeroed device fault word (uint32 as one int32 element); pass it as ``fault=`` and test it with ``_lib.check_fault``."""
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
 def gemm(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, precision="bf16x3", residual=None, residual_planes=None,
-         out_f32=False, out_planes=True, out_lo=True, small=None):
+         out_f32=False, out_planes=True, out_lo=True, small=None, fault=None):
     """C = act(A W^T + bias) + residual.  A planes [M,K], W planes [N,K].  -> (C_hi, C_lo, C_f32)."""
     M, K = a_hi.shape
     N = w_hi.shape[0]
@@ -88,6 +93,7 @@ def gemm(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, precision="bf16x3", residu
     g.A_hi, g.A_lo, g.lda = a_hi.data_ptr(), _lib.ptr(a_lo), a_hi.stride(0)
     g.W_hi, g.W_lo, g.ldw = w_hi.data_ptr(), _lib.ptr(w_lo), w_hi.stride(0)
     g.bias, g.act = _lib.ptr(bias), ACTS[act]
+    g.fault = _lib.ptr(fault)
     if residual is not None:
         g.R_f32, g.ldr = _f32c(residual).data_ptr(), residual.stride(0)
     if residual_planes is not None:
@@ -110,7 +116,7 @@ def gemm(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, precision="bf16x3", residu
     return c_hi, c_lo, c_f32
 
 
-def gemm_ln(a_hi, a_lo, w_hi, w_lo, bias, residual_planes, gamma, beta, eps, precision="fp16", f32=False, out=None):
+def gemm_ln(a_hi, a_lo, w_hi, w_lo, bias, residual_planes, gamma, beta, eps, precision="fp16", f32=False, out=None, fault=None):
     """LayerNorm(A W^T + bias + residual) in one launch -> (y_hi, y_lo, y_f32).  N == 768, M >= 2048.
     ``out`` = (y_hi, y_lo) to write into (may be the residual planes themselves, as the decoder does)."""
     M, K = a_hi.shape
@@ -121,6 +127,7 @@ def gemm_ln(a_hi, a_lo, w_hi, w_lo, bias, residual_planes, gamma, beta, eps, pre
     g.A_hi, g.A_lo, g.lda = a_hi.data_ptr(), _lib.ptr(a_lo), a_hi.stride(0)
     g.W_hi, g.W_lo, g.ldw = w_hi.data_ptr(), _lib.ptr(w_lo), w_hi.stride(0)
     g.bias, g.act = bias.data_ptr(), _lib.ACT_NONE
+    g.fault = _lib.ptr(fault)
     g.R_hi, g.R_lo, g.ldr = residual_planes[0].data_ptr(), residual_planes[1].data_ptr(), residual_planes[0].stride(0)
     pd = plane_dtype(precision)
     y_hi, y_lo = out if out is not None else (torch.empty((M, N), dtype=pd, device=dev), torch.empty((M, N), dtype=pd, device=dev))

@@ -29,6 +29,9 @@ Extra keyword-only arguments (all optional; defaults reproduce the reference cal
                     logits / strings: didi_amd/validation.py rounds them with a cross-entropy epilogue
   target_len        reply length S, overriding ``len(range(C)[:max_len])``: lets a batch whose context padding was trimmed
                     (didi_amd/hostio.py) keep the reply length of the untrimmed batch
+  (device faults)   kernels report run-time conditions only the device sees (DIDI_FAULT_*: LayerNorm exchange timeout, fp16
+                    range) in a fault word; the string-returning path checks it before decoding, the tensor-returning paths
+                    (raw_output / return_ids / return_x0) stay sync-free: call ``model.check_fault()`` for the verdict
   clamp             per-step clamp extension of BASELINE config 4 (NOT in the reference): after every denoiser
                     call x0 <- emb[argmax(classifier(x0))] before the sampler update
 """
@@ -129,6 +132,7 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
             a.argmax_partial, a.ids64 = b["partial"].data_ptr(), ids.data_ptr()
         if clamp:
             a.clamp_emb = model.emb.weight.data_ptr()
+        a.fault = b["fault"].data_ptr()
         if _prof is not None:  # bench.py: HIP events around the GEMM launches of one denoiser call
             a.prof_call, a.prof_events_host, a.prof_capacity = _prof.call, _prof.events, _prof.capacity
             a.prof_used_host = C.pointer(_prof.used)
@@ -147,6 +151,7 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
     if return_ids:
         lengths = ops.first_eos(ids, eos_id) if eos_id is not None else torch.full((B,), S, dtype=torch.int32, device=dev)
         return ids, lengths
+    model.check_fault("sample")  # device-side verdict (exchange timeout, fp16 range) before anything is decoded
     lengths = ops.first_eos(ids, eos_id).cpu().tolist()  # the path's single D2H sync
     ids_host = ids.cpu()
     replies = tokenizer.batch_decode([ids_host[i, : lengths[i]] for i in range(B)], skip_special_tokens=skip_special)
@@ -179,6 +184,7 @@ def _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp=False):
         fa.kv_hi, fa.kv_lo, fa.ctx_mask = b["kv_hi"].data_ptr(), b["kv_lo"].data_ptr(), b["mask32"].data_ptr()
         fa.workspace, fa.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
         fa.x0_f32 = x0.data_ptr()
+        fa.fault = b["fault"].data_ptr()
         _lib.check(lib.didi_decoder_forward(C.byref(model._dec), C.byref(fa), _lib.current_stream()), "decoder_forward")
         if clamp:
             clamp_x0()

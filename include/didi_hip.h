@@ -9,9 +9,15 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in _host; `stream` is a hipStream_t
  *     passed as void* (NULL = the default stream); all work is enqueued asynchronously on it.
- *   - nothing here allocates, frees or synchronises; workspaces are sized by the *_bytes queries
- *     and passed in.  No global mutable state: calls on different streams/devices are independent.
+ *   - nothing here allocates, frees or synchronises (didi_fault_read, a host-side helper, is the one call that
+ *     waits for the stream); workspaces are sized by the *_bytes queries and passed in.  Calls on different
+ *     streams/devices are independent.  Process-wide state is limited to (a) the tuning switches of
+ *     didi_set_option (defaults = the production path; nothing reads the environment), (b) a per-device cache of
+ *     device attributes (CU count, the > 64 KiB LDS opt-ins), filled on the first call on each device, and (c) the
+ *     per-device scratch array of didi_round_argmax_static.
  *   - return value: DIDI_OK (0) or a negative DIDI_ERR_* code.  No exceptions cross the boundary.
+ *   - run-time conditions that only the device can see (see DIDI_FAULT_*) are reported through an optional
+ *     device-side fault word that the caller zeroes, passes in, and reads back after synchronising.
  *   - "split planes": an fp32 tensor [R, W] held as two bf16 tensors hi,lo [R, W] with
  *     value = hi + lo (hi = RNE bf16 of the value).  lo pointers may be NULL where stated: then
  *     only hi is read/written ("bf16" precision); with both, GEMMs and attention add the hi*lo and
@@ -28,15 +34,46 @@
 extern "C" {
 #endif
 
-#define DIDI_ABI_VERSION 3
+#define DIDI_ABI_VERSION 4
 
 enum {
     DIDI_OK = 0,
     DIDI_ERR_BAD_ARG = -1,     /* NULL where required, size/alignment constraint violated */
     DIDI_ERR_UNSUPPORTED = -2, /* shape outside what the kernels are built for */
     DIDI_ERR_LAUNCH = -3,      /* hipLaunchKernel reported an error */
-    DIDI_ERR_WORKSPACE = -4    /* workspace too small */
+    DIDI_ERR_WORKSPACE = -4,   /* workspace too small */
+    DIDI_ERR_FAULT = -5        /* didi_fault_read: the device-side fault word is non-zero (bits: DIDI_FAULT_*) */
 };
+
+/* Device-side fault word (uint32_t in device memory, owned and zeroed by the caller; NULL = not reported).
+ * Kernels OR bits into it and never clear it, so one word can watch a whole sampling loop:
+ *   DIDI_FAULT_LN_EXCHANGE  a workgroup of didi_gemm_ln gave up waiting for its band mates' row statistics (the launch
+ *                           was not co-resident: another kernel or a CU mask held CUs).  The rows it owned are NaN.
+ *   DIDI_FAULT_FP16_RANGE   a GEMM epilogue in DIDI_PREC_FP16 produced |value| > 65504 for an fp16 plane.  The planes
+ *                           hold the value SATURATED to +-65504 (never inf); results downstream are not to be trusted
+ *                           at fp16 precision: rerun in DIDI_PREC_BF16X3 (bf16 planes have fp32's range).
+ * No reference counterpart: the reference computes in fp32 on one stream. */
+enum { DIDI_FAULT_LN_EXCHANGE = 1, DIDI_FAULT_FP16_RANGE = 2 };
+/* Host-side helper: waits for `stream`, copies the word to *bits_host (may be NULL) and returns DIDI_OK when it is 0,
+ * DIDI_ERR_FAULT otherwise.  The ONE call of this library that synchronises. */
+int didi_fault_read(const uint32_t* fault, uint32_t* bits_host, void* stream);
+const char* didi_fault_string(uint32_t bits);
+
+/* Process-wide tuning switches (A/B measurements, tools/): every default selects the production path and no caller
+ * needs them.  They replace the environment variables of ABI <= 3; the library itself never reads the environment.
+ * Not thread-safe against concurrent launches. */
+enum {
+    DIDI_OPT_GEMM_LN = 0,      /* 1: fused projection + LayerNorm where supported (didi_gemm_ln); 0: GEMM then didi_layernorm */
+    DIDI_OPT_GEMM_SMALL = 1,   /* 1: split-K small-batch form below DIDI_OPT_SMALL_MAX_M rows */
+    DIDI_OPT_GEMM_BIG = 2,     /* 1: 256x192 tile from DIDI_OPT_BIG_MIN_M rows on; 0: 128x128 everywhere */
+    DIDI_OPT_GEMM_PP = 3,      /* 1: staggered wave groups (gemm_pp_kernel); 0: in-phase loop (gemm_big_kernel) */
+    DIDI_OPT_GEMM_MT = 4,      /* 4 (default) or 2: 64-row wave tiles along M of the in-phase big tile */
+    DIDI_OPT_BIG_MIN_M = 5,    /* default 2048 */
+    DIDI_OPT_SMALL_MAX_M = 6,  /* default 2048 */
+    DIDI_OPT_COUNT = 7
+};
+int didi_set_option(int key, int value);
+int didi_get_option(int key, int* value);
 
 /* Operand precision of GEMMs and attention.  BF16 / BF16X3: bf16 planes, 1 / 3 MFMA products.
  * FP16: fp16 planes (hi = RNE fp16 of the value, lo = fp16 of the remainder), ONE product on the hi
@@ -155,14 +192,16 @@ typedef struct didi_gemm_args {
     float* C_f32;          /* or NULL */
     uint16_t *C_hi, *C_lo; /* or NULL */
     int ldc;
+    uint32_t* fault;       /* device fault word (DIDI_FAULT_*) or NULL */
 } didi_gemm_args;
 int didi_gemm_bf16(const didi_gemm_args* a, void* stream);
 
 /* y = LayerNorm(A W^T + bias + residual): BertSelfOutput / BertOutput in one launch -- `dense` +
  * dropout(eval) + `LayerNorm(hidden_states + input_tensor)` (HF:models/bert/modeling_bert.py:284-295,342-353).
  * The GEMM keeps its 256x192 tiles; the four workgroups that share a 256-row band exchange exact per-row
- * partial statistics through `stats` and an arrival counter, then each normalises its own 192 columns
- * from registers: the pre-norm tensor and the separate LayerNorm pass never touch HBM.
+ * partial statistics through `stats` (epoch-tagged 8-byte granules: the data is the flag, no counter and no
+ * fence), then each normalises its own 192 columns from registers: the pre-norm tensor and the separate
+ * LayerNorm pass never touch HBM.
  * Takes a didi_gemm_args with act = NONE, residual PLANES (R_hi, R_lo), bias, and no C_* outputs; writes
  * split planes y_hi / y_lo (format of the precision; may alias the residual planes) and, if not NULL, fp32
  * y_f32, all [M, N] dense.  Supported (didi_gemm_ln_supported != 0): N == 768 (BertConfig hidden size: the
@@ -171,9 +210,11 @@ int didi_gemm_bf16(const didi_gemm_args* a, void* stream);
  * statistics travel as 8-byte {tag = epoch, value} words.  On entry no word of it may carry `epoch` in its upper half:
  * zero the buffer once (hipMemsetAsync), then pass epoch = 1, 2, 3, ... to successive calls that share it;
  * epoch == 0 makes the call zero the buffer itself and use tag 1 (stand-alone use).
- * A launch never holds more than one workgroup per CU (rows are processed in chunks), so the workgroups that
- * wait for each other are always co-resident; the wait is bounded in any case, and rows whose wait ran out come back
- * as NaN. */
+ * A launch never holds more than one workgroup per CU of the CURRENT device (rows are processed in chunks), so the
+ * workgroups that wait for each other are co-resident as long as the stream has the device to itself; a concurrent
+ * kernel on another stream or a CU-masked stream can break that.  The wait is bounded in any case: rows whose wait ran
+ * out come back as NaN AND DIDI_FAULT_LN_EXCHANGE is raised in a->fault (check it with didi_fault_read; callers that
+ * share the device between streams switch the fusion off: didi_set_option(DIDI_OPT_GEMM_LN, 0)). */
 int didi_gemm_ln_supported(int M, int N, int K, int precision);
 size_t didi_gemm_ln_stats_bytes(int M);
 int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, uint16_t* y_hi,
@@ -328,6 +369,7 @@ typedef struct didi_forward_args {
     void** prof_events_host;
     int prof_capacity;
     int* prof_used_host;
+    uint32_t* fault; /* device fault word (DIDI_FAULT_*) or NULL */
 } didi_forward_args;
 int didi_decoder_forward(const didi_decoder* dec, const didi_forward_args* a, void* stream);
 
@@ -377,6 +419,7 @@ typedef struct didi_sample_args {
      * row of its rounded token, x0 <- emb[argmax(classifier(x0))], before the sampler update.  Needs the
      * rounding fields above (cls_*, V, argmax_partial, ids64 as scratch, x0_hi/x0_lo). */
     const float* clamp_emb;
+    uint32_t* fault; /* device fault word (DIDI_FAULT_*) or NULL; watched over the whole loop */
 } didi_sample_args;
 int didi_sample(const didi_decoder* dec, const didi_sample_args* a, void* stream);
 

@@ -29,8 +29,26 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert getattr(raw, name) is not None
-    assert _lib.lib.didi_version() == 3
+    assert _lib.lib.didi_version() == _lib.ABI_VERSION == 4
     assert b"workspace" in _lib.lib.didi_error_string(-4)
+    assert b"fault" in _lib.lib.didi_error_string(_lib.ERR_FAULT)
+    assert b"co-resident" in _lib.lib.didi_fault_string(_lib.FAULT_LN_EXCHANGE)
+    assert b"fp16" in _lib.lib.didi_fault_string(_lib.FAULT_FP16_RANGE)
+    assert _lib.lib.didi_fault_string(0) == b"no fault"
+
+
+def test_options_are_explicit_and_validated():
+    """The library reads no environment variable: tuning switches go through didi_set_option (host-only, no GPU needed)."""
+    from didi_amd import _lib
+
+    assert _lib.get_option("GEMM_LN") == 1 and _lib.get_option("BIG_MIN_M") == 2048 and _lib.get_option("GEMM_MT") == 4
+    _lib.set_option("GEMM_LN", 0)
+    assert _lib.get_option("GEMM_LN") == 0
+    _lib.set_option("GEMM_LN", 1)
+    assert _lib.lib.didi_set_option(99, 1) == -1 and _lib.lib.didi_set_option(_lib.OPTIONS["GEMM_MT"], 3) == -1
+    src = "".join(open(os.path.join(ROOT, "didi_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "didi_amd", "csrc"))
+                  if f.endswith((".hip", ".hpp")))
+    assert "getenv" not in src
 
 
 def test_size_queries_without_gpu():

@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from didi_amd.dist import gather_ids, philox_offset, shard_bounds
+from didi_amd.dist import gather_ids, philox_offset, sample_sharded, shard_bounds
 
 
 def test_shard_bounds_cover_batch():
@@ -51,3 +51,76 @@ def test_gather_ids_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(got) == [(0, True, True), (1, True, True)]
+
+
+def _stub_sample(local, model, mode, step_freq, noise_factor=1, max_len=-1, tokenizer=None, return_ids=False, philox_offset=0, **kw):
+    """Stands in for didi_amd.sampling.sample: ids that encode which dialog and which Philox range produced them."""
+    assert return_ids and mode == "euler" and step_freq == 10 and model == "the-model"
+    B, C = local.input_ids.shape
+    S = len(range(C)[:max_len])
+    ids = local.input_ids[:, :1] * 1000 + torch.arange(S)[None, :]
+    ids[:, -1] = philox_offset >> 40  # the rank whose counter range was used
+    lengths = (local.input_ids[:, 0] % S + 1).to(torch.int32)
+    return ids, lengths
+
+
+def _sharded_worker(rank, world, port, B, C, local_only, q):
+    from didi_amd.synthetic import RawContext
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gids = (torch.arange(B * C, dtype=torch.int64).reshape(B, C) % 97) + 3 + torch.arange(B)[:, None] * 100
+    gmask = torch.ones(B, C, dtype=torch.int64)
+    a, b = shard_bounds(B, world, rank)
+    if local_only:  # the rank holds (and would upload) only its own rows
+        ids, lengths = sample_sharded(RawContext(gids[a:b], gmask[a:b]), "the-model", "euler", 10, rank=rank, world=world,
+                                      max_len=C, eos_id=2, global_batch=B, sample_fn=_stub_sample)
+    else:
+        ids, lengths = sample_sharded(RawContext(gids, gmask), "the-model", "euler", 10, rank=rank, world=world, max_len=C,
+                                      eos_id=2, sample_fn=_stub_sample)
+    want = gids[:, :1] * 1000 + torch.arange(C)[None, :]
+    owner = torch.tensor([r for r in range(world) for _ in range(*shard_bounds(B, world, r))])
+    want[:, -1] = owner
+    ok = tuple(ids.shape) == (B, C) and torch.equal(ids, want) and torch.equal(lengths, (gids[:, 0] % C + 1).to(torch.int32))
+    bad_shard = False
+    if local_only and b - a > 0:
+        try:
+            sample_sharded(RawContext(gids[a:b][:-1], gmask[a:b][:-1]), "the-model", "euler", 10, rank=rank, world=world, max_len=C,
+                           global_batch=B, sample_fn=_stub_sample)
+        except ValueError:
+            bad_shard = True
+    q.put((rank, bool(ok), bad_shard or not local_only or b - a == 0))
+    dist.destroy_process_group()
+
+
+def _run(target, args, world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(got)
+
+
+def test_sample_sharded_world2_gloo_global_batch_uneven():
+    """sample_sharded itself under world_size 2: uneven shards (4 + 3), rows come back in global order on every rank and each
+    rank sampled with its own Philox range."""
+    assert _run(_sharded_worker, (7, 6, False), 2) == [(0, True, True), (1, True, True)]
+
+
+def test_sample_sharded_world2_gloo_local_shards():
+    """Each rank passes only its own rows (what bench.py uploads); a shard of the wrong size is rejected."""
+    assert _run(_sharded_worker, (5, 4, True), 2) == [(0, True, True), (1, True, True)]
+
+
+def test_sample_sharded_world2_gloo_empty_shard():
+    """B = 1 < world: rank 1 has nothing to sample and still takes part in the gather."""
+    assert _run(_sharded_worker, (1, 4, False), 2) == [(0, True, True), (1, True, True)]
+    assert _run(_sharded_worker, (1, 4, True), 2) == [(0, True, True), (1, True, True)]

@@ -1,0 +1,178 @@
+"""GPU parity at the BENCHMARKED model size (BASELINE configs[1..3]) against the CPU oracle, through the C ABI.
+
+The fixtures from the reference pin the oracle on small models (tests/test_oracle_golden.py); here the oracle is the
+reference for the cfg2-sized model (12 x 768 decoder, 2 x 1280 encoder, V = 8008 / 50 000) that bench.py times:
+  * token-id agreement >= 99.9 % and every denoiser input x_t within rel-L2 1e-3 (fp16) / 1e-4 (bf16x3) over a whole
+    T = 2000, step_freq = 10 loop (201 denoiser calls), ddpm and euler (= the "DDIM 200-step" of BASELINE configs[2]);
+  * one denoiser call + rounding at the exact bench shape B = 256, S = C = 64 (M = 16 384 rows: 64 row bands = 256
+    workgroups = every CU in one didi_gemm_ln launch), finite everywhere, no device fault;
+  * BASELINE configs[3]'s shape: V = 50 000, S = C = 84, B = 1024 (M = 86 016) with the per-step clamp extension.
+Dialogs are independent (no cross-sample op on the path), so the oracle runs a slice of the batch the GPU runs.
+"""
+import time
+
+import pytest
+import torch
+
+from golden_util import ListNoise, config1, config1_state_dict, config_to_oracle_config
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _ctx(ids, mask):
+    from didi_amd.synthetic import RawContext
+
+    return RawContext(ids.cuda(), mask.cuda())
+
+
+@pytest.mark.parametrize("mode", ["ddpm", "euler"])
+def test_cfg2_size_loop_ids_and_xt_vs_oracle(mode):
+    """cfg2-sized model, T = 2000, step_freq = 10 (201 calls).  The GPU samples 40 dialogs (M = 2560 rows: the 256x192 GEMM
+    tile with the fused projection + LayerNorm, the path bench.py runs); the oracle samples the first 16 with the same
+    injected noise: 1024 token positions, so the 99.9 % bar allows ONE differing id."""
+    from didi_amd.config import DiDiConfig
+    from didi_amd.model import DiDiSampler
+    from didi_amd.sampling import sample
+    from didi_amd.synthetic import synthetic_batch, synthetic_state_dict
+    from oracle.model import OracleDiDi
+    from oracle.sampling import Context, sample as oracle_sample
+
+    cfg = DiDiConfig(diffusion_steps=2000)
+    sd = synthetic_state_dict(cfg, seed=1234)
+    B, Bo, C, S, f = 40, 16, 64, 64, 10
+    ids, mask = synthetic_batch(B, C, cfg.vocab, seed=11)
+    n_calls = len(range(cfg.diffusion_steps, 1, -f)) + 1
+    n_draws = n_calls if mode == "ddpm" else n_calls + 1
+    g = torch.Generator().manual_seed(21)
+    noise = torch.randn(n_draws, B, S, cfg.dec_dim, generator=g)
+    t0 = time.time()
+    want_trace = []
+    want = oracle_sample(Context(ids[:Bo], mask[:Bo]), OracleDiDi(sd, config_to_oracle_config(cfg)), mode, f, max_len=S,
+                         raw_output=True, noise_source=ListNoise([noise[i, :Bo] for i in range(n_draws)]), trace=want_trace)
+    want_ids = want.argmax(-1)
+    top2 = want.topk(2, -1).values
+    print(f"\n[cfg2 {mode} f={f}] oracle: {n_calls} calls x {Bo} dialogs in {time.time() - t0:.0f} s; "
+          f"median top-2 logit gap {float((top2[..., 0] - top2[..., 1]).median()):.3f}")
+    assert len(want_trace) == n_calls
+    noise_dev = noise.cuda()
+    for precision, xt_bar in (("bf16x3", 1e-4), ("fp16", 1e-3)):
+        model = DiDiSampler(sd, cfg, device="cuda", precision=precision)
+        trace = []
+        got, _ = sample(_ctx(ids, mask), model, mode, f, max_len=S, noise=noise_dev, return_ids=True, trace=trace)
+        model.check_fault(f"cfg2 {mode} {precision}")
+        flips = int((got[:Bo].cpu() != want_ids).sum())
+        worst = max(rel_l2(a[:Bo], b) for a, b in zip(trace, want_trace))
+        print(f"[cfg2 {mode} f={f} {precision}] ids differ on {flips} of {want_ids.numel()} positions "
+              f"({100 - 100.0 * flips / want_ids.numel():.3f} % agree); max x_t rel-L2 over {n_calls} calls {worst:.3e}")
+        assert worst <= xt_bar
+        assert 1.0 - flips / want_ids.numel() >= 0.999
+        del model, trace
+
+
+def test_bench_shape_single_call_full_chip():
+    """B = 256, S = C = 64 (bench.py's shape): one denoiser call + rounding in fp16.  Every output finite, no device fault, and
+    the first 4 dialogs agree with the oracle; then the same through bf16x3 at 1e-4."""
+    from didi_amd import ops
+    from didi_amd.config import DiDiConfig
+    from didi_amd.model import DiDiSampler
+    from didi_amd.synthetic import synthetic_batch, synthetic_state_dict
+    from oracle.model import OracleDiDi
+
+    cfg = DiDiConfig(diffusion_steps=2000)
+    sd = synthetic_state_dict(cfg, seed=1234)
+    B, Bo, C, S = 256, 4, 64, 64
+    ids, mask = synthetic_batch(B, C, cfg.vocab, seed=0xBADB01)
+    g = torch.Generator().manual_seed(5)
+    x_t = torch.randn(B, S, cfg.dec_dim, generator=g)
+    tids = torch.randint(1, 2001, (B, 1), generator=g)
+    oracle = OracleDiDi(sd, config_to_oracle_config(cfg))
+    want, _ = oracle(encoder_input_ids=ids[:Bo], encoder_attention_mask=mask[:Bo], decoder_inputs_embeds=x_t[:Bo], time_ids=tids[:Bo])
+    want_ids = oracle.classifier(want).argmax(-1)
+    for precision, bar in (("fp16", 2e-3), ("bf16x3", 1e-4)):
+        model = DiDiSampler(sd, cfg, device="cuda", precision=precision)
+        out, _ = model(encoder_input_ids=ids.cuda(), encoder_attention_mask=mask.cuda(), decoder_inputs_embeds=x_t.cuda(),
+                       time_ids=tids.cuda())
+        model.check_fault(f"bench shape {precision}")
+        assert bool(torch.isfinite(out).all())
+        hi, lo = ops.split(out.view(B * S, -1), dtype=model._pd)
+        got_ids = ops.round_argmax(hi, lo if precision == "bf16x3" else None, model._cls.hi, model._cls.lo, precision).view(B, S)
+        err = rel_l2(out[:Bo], want)
+        match = (got_ids[:Bo].cpu() == want_ids).float().mean().item()
+        # the ids of a random x_t are near-uniform: no token may dominate (a poisoned row would round to token 0)
+        top_share = got_ids.flatten().bincount(minlength=cfg.vocab).max().item() / got_ids.numel()
+        print(f"\n[bench shape {precision}] x0_hat rel-L2 {err:.3e}  id match {match:.4f} on {want_ids.numel()}  most frequent id share {top_share:.4f}")
+        assert err <= bar and match >= 0.99 and top_share < 0.05
+        del model
+
+
+def test_config3_shape_large_vocab_clamp():
+    """BASELINE configs[3]: V = 50 000, S = C = 84, B = 1024 (M = 86 016 rows), per-step clamp ON, two denoiser calls
+    (T = 2): rounding GEMM 6.6 TFLOP per call with the logits (17 GB) never written.  The oracle runs the first 2 dialogs."""
+    from didi_amd.config import DiDiConfig
+    from didi_amd.model import DiDiSampler
+    from didi_amd.sampling import sample
+    from didi_amd.synthetic import synthetic_batch, synthetic_state_dict
+    from oracle.model import OracleDiDi
+    from oracle.sampling import Context, sample as oracle_sample
+
+    cfg = DiDiConfig(vocab=50000, diffusion_steps=2)
+    sd = synthetic_state_dict(cfg, seed=4321)
+    B, Bo, C, S = 1024, 2, 84, 84
+    ids, mask = synthetic_batch(B, C, cfg.vocab, seed=17)
+    g = torch.Generator().manual_seed(33)
+    noise = torch.randn(2, B, S, cfg.dec_dim, generator=g)
+    want_trace = []
+    want = oracle_sample(Context(ids[:Bo], mask[:Bo]), OracleDiDi(sd, config_to_oracle_config(cfg)), "ddpm", 1, max_len=S,
+                         raw_output=True, noise_source=ListNoise([noise[0, :Bo], noise[1, :Bo]]), trace=want_trace, clamp=True)
+    model = DiDiSampler(sd, cfg, device="cuda", precision="fp16")
+    trace = []
+    got, lengths = sample(_ctx(ids, mask), model, "ddpm", 1, max_len=S, noise=noise.cuda(), return_ids=True, trace=trace, clamp=True)
+    model.check_fault("config3 shape")
+    assert tuple(got.shape) == (B, S) and int(got.min()) >= 0 and int(got.max()) < cfg.vocab
+    match = (got[:Bo].cpu() == want.argmax(-1)).float().mean().item()
+    # call 1's input depends on call 0's clamped ids: a differing id there moves x_t, so report both and bound the first call
+    e0 = rel_l2(trace[0][:Bo], want_trace[0])
+    e1 = rel_l2(trace[1][:Bo], want_trace[1])
+    print(f"\n[config3 shape fp16, clamp] id match {match:.4f} on {Bo * S} positions; x_t rel-L2 call 0 {e0:.3e}, call 1 {e1:.3e}")
+    assert e0 <= 1e-6  # the initial noise, scaled
+    assert match >= 0.97  # random-init weights at V = 50 000: top-2 gaps are small, a clamp flip feeds back (parity unpinned by the reference)
+    top_share = got.flatten().bincount(minlength=cfg.vocab).max().item() / got.numel()
+    assert top_share < 0.05
+
+
+def test_id_agreement_config1_2208_positions():
+    """Token-id agreement over 2208 positions (config-1 model, 96 dialogs x 23, T = 50, identical injected noise, fp32 CPU
+    oracle): bf16x3 and fp16 must hold >= 99.9 %; plain bf16 is reported (it does not: DESIGN.md section 2)."""
+    from didi_amd.model import DiDiSampler
+    from didi_amd.sampling import sample
+    from oracle.model import OracleDiDi
+    from oracle.sampling import Context, sample as oracle_sample
+
+    cfg, sd = config1(), config1_state_dict()
+    B, C = 96, 24
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(3, cfg.vocab, (B, C), generator=g)
+    mask = torch.ones(B, C, dtype=torch.long)
+    lens = torch.randint(8, C + 1, (B,), generator=g)
+    for b in range(B):
+        mask[b, lens[b]:] = 0
+    torch.manual_seed(5)
+    draws = [torch.randn(B, C - 1, cfg.dec_dim) for _ in range(cfg.diffusion_steps + 1)]
+    trace = []
+    want = oracle_sample(Context(ids, mask), OracleDiDi(sd, config_to_oracle_config(cfg)), "ddpm", 1, raw_output=True,
+                         noise_source=ListNoise(draws), trace=trace).argmax(-1)
+    n_calls = len(trace)
+    for precision, bar in (("bf16x3", 0.999), ("fp16", 0.999), ("bf16", 0.97)):
+        model = DiDiSampler(sd, cfg, device="cuda", precision=precision)
+        tr = []
+        got, _ = sample(_ctx(ids, mask), model, "ddpm", 1, noise=torch.stack(draws[:n_calls]), return_ids=True, trace=tr)
+        model.check_fault(precision)
+        diff = int((got.cpu() != want).sum())
+        worst = max(rel_l2(a, b) for a, b in zip(tr, trace))
+        print(f"\n[id agreement {precision}] ids differ {diff} of {want.numel()} ({100 - 100.0 * diff / want.numel():.3f} % agree)  max x_t rel-L2 {worst:.3e}")
+        assert 1.0 - diff / want.numel() >= bar

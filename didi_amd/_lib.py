@@ -144,6 +144,9 @@ SYMBOLS = [
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("didi_round_argmax", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("didi_round_argmax_static_max_bytes", C.c_size_t, []),
+    ("didi_round_argmax_static", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("didi_first_eos", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     ("didi_attention", C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     ("didi_decoder_workspace_bytes", C.c_size_t, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int]),

@@ -239,6 +239,18 @@ int didi_round_argmax(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const
                       const uint16_t* W_lo, int ldw, int M, int V, int K, int precision, void* partial,
                       int64_t* ids64, int32_t* ids32, void* stream);
 
+/* didi_round_argmax for callers that cannot allocate (no counterpart in the reference: it is for code under HIP graph capture,
+ * tight serving loops and harnesses that forbid hipMalloc, which have nowhere to get the `partial` workspace from).
+ * Same arithmetic, same kernels, same results as didi_round_argmax; the (max, index) partials live in a file-scope device
+ * array of didi_round_argmax_static_max_bytes() = 16 MiB that every GPU the library runs on holds until the process ends.
+ * Shapes with didi_round_argmax_bytes(M, V) = M * ceil(V / 128) * 8 above that limit are rejected with DIDI_ERR_WORKSPACE
+ * (it covers M = 16384 at V = 8008 and M = 5376 at V = 50000).  Allocates nothing, frees nothing, synchronises nothing.
+ * Calls that overlap on one GPU (two streams, two threads) share the array and race: serialise them.  The first call on a
+ * device resolves the array's device address (hipGetSymbolAddress): make it outside graph capture. */
+size_t didi_round_argmax_static_max_bytes(void);
+int didi_round_argmax_static(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uint16_t* W_hi, const uint16_t* W_lo,
+                             int ldw, int M, int V, int K, int precision, int64_t* ids64, int32_t* ids32, void* stream);
+
 /* The same GEMM with a cross-entropy epilogue: what `DiDi.validation_step` (src/diffusion/model.py:248-254) computes
  * from `sample(..., raw_output=True)` -- `logits.argmax(-1)` and the per-token terms of `calculate_batch_ce`
  * (src/metrics.py:91-93) -- without writing the [M, V] logits:

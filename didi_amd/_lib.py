@@ -18,7 +18,7 @@ i32p = C.POINTER(C.c_int32)
 i64p = C.POINTER(C.c_int64)
 
 OK = 0
-PREC_BF16, PREC_FP16, PREC_BF16X3 = 1, 2, 3
+PREC_BF16, PREC_FP16, PREC_BF16X3, PREC_FP16X2, PREC_FP16X3 = 1, 2, 3, 4, 5
 FMT_BF16, FMT_FP16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_TANH, ACT_RELU, ACT_GELU_NEW = 0, 1, 2, 3, 4
 STEP_NONE, STEP_INIT, STEP_DDPM, STEP_EULER = 0, 1, 2, 3

@@ -83,7 +83,7 @@ def load_state(path):
     return ckpt, {}
 
 
-def load_lightning_checkpoint(path, device="cuda", precision="fp16", **overrides):
+def load_lightning_checkpoint(path, device="cuda", precision="fp16x2", **overrides):
     """``DiDi.load_from_checkpoint`` for the sampler path -> DiDiSampler."""
     from .model import DiDiSampler
 

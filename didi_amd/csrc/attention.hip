@@ -299,7 +299,7 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
     DIDI_CHECK_ARG(a->scale >= 0.f && (reinterpret_cast<uintptr_t>(a->pos_bias) & 3) == 0);
     DIDI_CHECK_ARG(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo > 0 && a->ldo % 4 == 0);
     const bool x3 = a->precision == DIDI_PREC_BF16X3;
-    const bool f16 = a->precision == DIDI_PREC_FP16;
+    const bool f16 = a->precision == DIDI_PREC_FP16 || a->precision == DIDI_PREC_FP16X2;  // no weights here: x2 = one product
     DIDI_CHECK_ARG(x3 || f16 || a->precision == DIDI_PREC_BF16);
     if (x3) DIDI_CHECK_ARG(a->Q_lo && a->K_lo && a->V_lo && a->O_lo);
     const void* ptrs[6] = {a->Q_hi, a->Q_lo, a->K_hi, a->K_lo, a->V_hi, a->V_lo};

@@ -31,18 +31,17 @@ __device__ __forceinline__ float bf16_to_f32(u16 b) { return __builtin_bit_cast(
 __device__ __forceinline__ u16 f16_bits(float x) { return __builtin_bit_cast(u16, (_Float16)x); }
 __device__ __forceinline__ float f16_to_f32(u16 b) { return (float)__builtin_bit_cast(_Float16, b); }
 
-// fp16 planes saturate instead of overflowing: |x| > 65504 is stored as +-65504 (a NaN stays a NaN), so one outlier
-// feature cannot turn a row into inf -> NaN in the next LayerNorm.  GEMM epilogues also report it (DIDI_FAULT_FP16_RANGE).
+// fp16 planes saturate instead of overflowing.  MODE register bit 23 (FP16_OVFL): "an overflowed FP16 VALU result is clamped to
+// +-MAX_FP16 regardless of round mode, while still preserving true INF values" -- so v_cvt_f16_f32 of |x| > 65504 gives +-65504
+// at no cost per value (an explicit compare + select per value cost the issue-bound GEMM epilogues 7-11 % of the whole
+// sampler, tools/ab_bench.sh); true infinities and NaNs pass through.  Every kernel that writes fp16 planes sets the bit once per
+// wave; GEMM epilogues also track max |value| (one v_max3_f32 per two values) and report DIDI_FAULT_FP16_RANGE at the end.
 #define DIDI_F16_MAX 65504.0f
-__device__ __forceinline__ float sat_f16(float x) { return fabsf(x) > DIDI_F16_MAX ? copysignf(DIDI_F16_MAX, x) : x; }
-__device__ __forceinline__ bool over_f16(float x) { return fabsf(x) > DIDI_F16_MAX; }
+__device__ __forceinline__ void f16_saturate_mode() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1 /* hwreg(HW_REG_MODE, 23, 1) */, 1); }
+__device__ __forceinline__ float amax2(float m, float a, float b) { return fmaxf(fmaxf(m, fabsf(a)), fabsf(b)); }  // NaNs are ignored
 
-// `sat`: callers whose values are not bounded by construction (GEMM epilogues, fp32 -> plane splits) pass true; softmax
-// probabilities, attention outputs (convex combinations of saturated V rows) and LayerNorm outputs (|y| <= sqrt(H) |gamma| + |beta|)
-// skip the three extra VALU instructions per value.
-__device__ __forceinline__ void split2(float x, u16& hi, u16& lo, int f16 = 0, bool sat = false) {
+__device__ __forceinline__ void split2(float x, u16& hi, u16& lo, int f16 = 0) {
     if (f16) {
-        if (sat) x = sat_f16(x);
         hi = f16_bits(x);
         lo = f16_bits(x - f16_to_f32(hi));
     } else {
@@ -55,18 +54,18 @@ __device__ __forceinline__ float join2(u16 hi, u16 lo, int f16 = 0) {
 }
 
 // 4 consecutive values -> two 8-byte packs (hi plane, lo plane)
-__device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo, int f16 = 0, bool sat = false) {
+__device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo, int f16 = 0) {
     u16 h[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split2(v[i], h[i], l[i], f16, sat);
+    for (int i = 0; i < 4; ++i) split2(v[i], h[i], l[i], f16);
     hi = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
     lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
 // hi plane only (callers that do not keep the remainder)
-__device__ __forceinline__ uint2 pack4_hi(const float v[4], int f16 = 0, bool sat = false) {
+__device__ __forceinline__ uint2 pack4_hi(const float v[4], int f16 = 0) {
     u16 h[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) h[i] = f16 ? f16_bits(sat ? sat_f16(v[i]) : v[i]) : bf16_bits(v[i]);
+    for (int i = 0; i < 4; ++i) h[i] = f16 ? f16_bits(v[i]) : bf16_bits(v[i]);
     return make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
 }
 __device__ __forceinline__ void unpack4(uint2 p, float v[4], int f16 = 0) {

@@ -65,11 +65,12 @@ extern "C" int didi_philox_normal(float* out, size_t n, uint64_t seed, uint64_t 
 // ------------------------------------------------------------------ fp32 -> split planes
 // bytes per element: 4 read + 4 written.
 __global__ void __launch_bounds__(256) split_kernel(const float* src, u16* hi, u16* lo, size_t n4, int f16) {
+    if (f16) f16_saturate_mode();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(src)[i];
         const float f[4] = {v.x, v.y, v.z, v.w};
         uint2 h, l;
-        split4(f, h, l, f16, true);
+        split4(f, h, l, f16);
         reinterpret_cast<uint2*>(hi)[i] = h;
         if (lo) reinterpret_cast<uint2*>(lo)[i] = l;
     }
@@ -237,12 +238,13 @@ extern "C" int didi_rmsnorm(const float* x, const float* gamma, float eps, int M
 }
 
 __global__ void __launch_bounds__(256) mul_split_kernel(const float* a, const float* b, size_t n4, u16* y_hi, u16* y_lo, int f16) {
+    if (f16) f16_saturate_mode();
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const float4 u = reinterpret_cast<const float4*>(a)[i], w = reinterpret_cast<const float4*>(b)[i];
     const float y[4] = {u.x * w.x, u.y * w.y, u.z * w.z, u.w * w.w};
     uint2 h, l;
-    split4(y, h, l, f16, true);
+    split4(y, h, l, f16);
     reinterpret_cast<uint2*>(y_hi)[i] = h;
     if (y_lo) reinterpret_cast<uint2*>(y_lo)[i] = l;
 }

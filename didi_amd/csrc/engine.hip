@@ -172,14 +172,15 @@ extern "C" int didi_decoder_prepare_context(const didi_decoder* dec, const float
                                             void* workspace, size_t workspace_bytes, uint16_t* kv_hi, uint16_t* kv_lo,
                                             void* stream) {
     DIDI_CHECK_ARG(dec && ctx && workspace && kv_hi && dec->layers_host);
-    DIDI_CHECK_ARG(precision == DIDI_PREC_BF16 || precision == DIDI_PREC_FP16 || (precision == DIDI_PREC_BF16X3 && kv_lo));
+    DIDI_CHECK_ARG(precision == DIDI_PREC_BF16 || precision == DIDI_PREC_FP16 || precision == DIDI_PREC_FP16X2 ||
+                   (precision == DIDI_PREC_BF16X3 && kv_lo));
     if (!shapes_ok(dec, B, 1, C)) return DIDI_ERR_UNSUPPORTED;
     const size_t Mc = (size_t)B * C, H = dec->H;
     const size_t plane = al256(Mc * H * 2);
     if (workspace_bytes < 2 * plane) return DIDI_ERR_WORKSPACE;
     u16* c_hi = (u16*)workspace;
     u16* c_lo = (u16*)((char*)workspace + plane);
-    if (precision == DIDI_PREC_FP16) TRY(didi_split_fp16(ctx, c_hi, c_lo, Mc * H, stream));
+    if (precision == DIDI_PREC_FP16 || precision == DIDI_PREC_FP16X2) TRY(didi_split_fp16(ctx, c_hi, c_lo, Mc * H, stream));
     else TRY(didi_split_bf16(ctx, c_hi, c_lo, Mc * H, stream));
     for (int l = 0; l < dec->L; ++l) {
         const didi_decoder_layer& ly = dec->layers_host[l];
@@ -194,7 +195,7 @@ extern "C" int didi_decoder_prepare_context(const didi_decoder* dec, const float
 extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_args* a, void* stream) {
     DIDI_CHECK_ARG(dec && a && dec->layers_host && a->workspace && a->x0_f32 && a->kv_hi && a->ctx_mask);
     const int prec = a->precision;
-    DIDI_CHECK_ARG(prec == DIDI_PREC_BF16 || prec == DIDI_PREC_FP16 || (prec == DIDI_PREC_BF16X3 && a->kv_lo));
+    DIDI_CHECK_ARG(prec == DIDI_PREC_BF16 || prec == DIDI_PREC_FP16 || prec == DIDI_PREC_FP16X2 || (prec == DIDI_PREC_BF16X3 && a->kv_lo));
     DIDI_CHECK_ARG(!(a->x0_lo && !a->x0_hi));
     if (!shapes_ok(dec, a->B, a->S, a->C)) return DIDI_ERR_UNSUPPORTED;
     if (a->S > 0 && dec->pos_emb == nullptr) return DIDI_ERR_BAD_ARG;
@@ -202,7 +203,9 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
     if (a->workspace_bytes < w.total) return DIDI_ERR_WORKSPACE;
     const int M = a->B * a->S, H = dec->H, I = dec->I, D = H / dec->heads;
     const bool x3 = prec == DIDI_PREC_BF16X3;
-    const int fmt = prec == DIDI_PREC_FP16 ? DIDI_FMT_FP16 : DIDI_FMT_BF16;
+    const bool f16 = prec == DIDI_PREC_FP16 || prec == DIDI_PREC_FP16X2;
+    const int fmt = f16 ? DIDI_FMT_FP16 : DIDI_FMT_BF16;
+    const int attn_prec = prec == DIDI_PREC_FP16X2 ? DIDI_PREC_FP16 : prec;  // fp16x2 adds the weights' remainder; attention has no weights
     const size_t Mc = (size_t)a->B * a->C;
     Prof prof{a->prof_events_host, a->prof_capacity, 0};
 
@@ -224,7 +227,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         TRY(gemm(ly.qkv, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, w.qkv_hi,
                  x3 ? w.qkv_lo : nullptr, 3 * H, stream, &prof, w.small_ws, a->fault));
         didi_attn_args at{};
-        at.B = a->B; at.heads = dec->heads; at.Sq = a->S; at.Sk = a->S; at.D = D; at.precision = prec;
+        at.B = a->B; at.heads = dec->heads; at.Sq = a->S; at.Sk = a->S; at.D = D; at.precision = attn_prec;
         at.causal = 1; at.key_mask = nullptr;
         at.Q_hi = w.qkv_hi; at.Q_lo = x3 ? w.qkv_lo : nullptr; at.ldq = 3 * H;
         at.K_hi = w.qkv_hi + H; at.K_lo = x3 ? w.qkv_lo + H : nullptr; at.ldk = 3 * H;
@@ -263,6 +266,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
     if (s->euler) DIDI_CHECK_ARG(s->c2_host && s->x_state);
     if (s->ids64) DIDI_CHECK_ARG(s->cls_hi && s->argmax_partial && s->x0_hi && s->V > 0);
     if (s->ids64 && s->precision == DIDI_PREC_BF16X3) DIDI_CHECK_ARG(s->cls_lo && s->x0_lo);
+    if (s->ids64 && s->precision == DIDI_PREC_FP16X2) DIDI_CHECK_ARG(s->cls_lo);
     if (s->clamp_emb) DIDI_CHECK_ARG(s->ids64 && s->x0_hi && s->x0_lo);
     if (!shapes_ok(dec, s->B, s->S, s->C)) return DIDI_ERR_UNSUPPORTED;
     const size_t MH = (size_t)s->B * s->S * dec->H;
@@ -284,7 +288,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
         return didi_embed_gather(s->ids64, s->clamp_emb, 1.0f, nullptr, s->B * s->S, s->S, dec->H, s->x0_f32, stream);
     };
     auto split_x0 = [&]() -> int {
-        return s->precision == DIDI_PREC_FP16 ? didi_split_fp16(s->x0_f32, s->x0_hi, s->x0_lo, MH, stream)
+        return s->precision == DIDI_PREC_FP16 || s->precision == DIDI_PREC_FP16X2 ? didi_split_fp16(s->x0_f32, s->x0_hi, s->x0_lo, MH, stream)
                                               : didi_split_bf16(s->x0_f32, s->x0_hi, s->x0_lo, MH, stream);
     };
     auto set_prof = [&](int k) {
@@ -351,8 +355,11 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
         if (s->x0_hi) TRY(split_x0());
     }
     if (s->ids64) {
+        // the FINAL rounding of the fp16x2 mode multiplies all three products (once per batch: free): the ids then carry the
+        // loop's error only, not the operand rounding of the classifier GEMM on top of it
+        const int round_prec = s->precision == DIDI_PREC_FP16X2 && s->x0_lo && s->cls_lo ? DIDI_PREC_FP16X3 : s->precision;
         TRY(didi_round_argmax(s->x0_hi, s->x0_lo, dec->H, s->cls_hi, s->cls_lo, dec->H, s->B * s->S, s->V, dec->H,
-                              s->precision, s->argmax_partial, s->ids64, nullptr, stream));
+                              round_prec, s->argmax_partial, s->ids64, nullptr, stream));
     }
     return DIDI_OK;
 }

@@ -86,7 +86,7 @@ __device__ __forceinline__ void glds16(const u16* src, char* lds_dst) {
 // Accumulate one 128x128 output tile at (m0, n0).  Requires K % (NPASS == 3 ? 32 : 64) == 0.
 template <int NPASS, int NSTAGE, bool F16>
 __device__ __forceinline__ void tile_glds(const GemmParams& p, char* smem, int m0, int n0, f32x4 (&acc)[4][4]) {
-    constexpr int BKK = NPASS == 3 ? 32 : 64;
+    constexpr int BKK = NPASS == 1 ? 64 : 32;
     constexpr int ROWB = BKK * 2;              // bytes per LDS row
     constexpr int TILEB = 128 * ROWB;          // one operand tile
     constexpr int CPR = ROWB / 16;             // 16-byte chunks per row
@@ -109,7 +109,7 @@ __device__ __forceinline__ void tile_glds(const GemmParams& p, char* smem, int m
     for (int j = 0; j < IPW; ++j) {
         const int row = (wave * IPW + j) * RPI + lane / CPR;
         const int slot = lane % CPR;
-        const int g = NPASS == 3 ? (slot ^ ((0 - (row >> 2)) & 3)) : (slot ^ (row & 7));
+        const int g = NPASS != 1 ? (slot ^ ((0 - (row >> 2)) & 3)) : (slot ^ (row & 7));
         a_src[j] = (size_t)min(m0 + row, p.M - 1) * p.lda + g * 8;
         w_src[j] = (size_t)min(n0 + row, p.N - 1) * p.ldw + g * 8;
     }
@@ -125,6 +125,10 @@ __device__ __forceinline__ void tile_glds(const GemmParams& p, char* smem, int m
                 glds16(p.A_lo + k0 + a_src[j], st + 1 * TILEB + j * 1024);
                 glds16(p.W_hi + k0 + w_src[j], st + 2 * TILEB + j * 1024);
                 glds16(p.W_lo + k0 + w_src[j], st + 3 * TILEB + j * 1024);
+            } else if constexpr (NPASS == 2) {  // fp16x2: the activation remainder is not multiplied, its tile slot stays empty
+                glds16(p.A_hi + k0 + a_src[j], st + 0 * TILEB + j * 1024);
+                glds16(p.W_hi + k0 + w_src[j], st + 2 * TILEB + j * 1024);
+                glds16(p.W_lo + k0 + w_src[j], st + 3 * TILEB + j * 1024);
             } else {
                 glds16(p.A_hi + k0 + a_src[j], st + 0 * TILEB + j * 1024);
                 glds16(p.W_hi + k0 + w_src[j], st + 1 * TILEB + j * 1024);
@@ -134,8 +138,8 @@ __device__ __forceinline__ void tile_glds(const GemmParams& p, char* smem, int m
 
     // NSTAGE-deep ring: K-tiles t+1 .. t+NSTAGE-2 stay in flight across the barrier (counted vmcnt,
     // raw s_barrier: __syncthreads() would drain the DMA queue, cdna_hip_programming.md section 5)
-    constexpr int G = IPW * (NPASS == 3 ? 4 : 2);  // DMA instructions per stage per wave
-    static_assert(G == 8, "vmcnt immediates below assume 8 DMA instructions per stage");
+    constexpr int G = IPW * (NPASS == 3 ? 4 : NPASS == 2 ? 3 : 2);  // DMA instructions per stage per wave
+    static_assert(G == 8 || G == 6, "vmcnt immediates below assume 8 (or, fp16x2, 6) DMA instructions per stage");
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (s < nt) issue(s, s);
@@ -144,14 +148,14 @@ __device__ __forceinline__ void tile_glds(const GemmParams& p, char* smem, int m
         // this wave's share of K-tile t has landed once at most the younger stages remain outstanding
         const int ahead = min(NSTAGE - 2, nt - 1 - t);
         if (ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (ahead == 1) { if constexpr (G == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else { if constexpr (G == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
         __builtin_amdgcn_s_barrier();  // everyone's share has landed; ring slot of K-tile t-1 is free
         if (t + NSTAGE - 1 < nt) issue(t + NSTAGE - 1, nbuf);
         const char* st = smem + buf * STAGE_BYTES;
         buf = buf + 1 == NSTAGE ? 0 : buf + 1;
         nbuf = nbuf + 1 == NSTAGE ? 0 : nbuf + 1;
-        if constexpr (NPASS == 3) {
+        if constexpr (NPASS != 1) {
             const char *Ah = st, *Al = st + TILEB, *Wh = st + 2 * TILEB, *Wl = st + 3 * TILEB;
             bf16x8 whf[4], wlf[4], ahf[4], alf[4];
 #pragma unroll
@@ -161,14 +165,14 @@ __device__ __forceinline__ void tile_glds(const GemmParams& p, char* smem, int m
                 whf[i] = *reinterpret_cast<const bf16x8*>(Wh + wo);
                 wlf[i] = *reinterpret_cast<const bf16x8*>(Wl + wo);
                 ahf[i] = *reinterpret_cast<const bf16x8*>(Ah + ao);
-                alf[i] = *reinterpret_cast<const bf16x8*>(Al + ao);
+                if constexpr (NPASS == 3) alf[i] = *reinterpret_cast<const bf16x8*>(Al + ao);
             }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
                     acc[ni][mi] = mma16<F16>(wlf[ni], ahf[mi], acc[ni][mi]);
-                    acc[ni][mi] = mma16<F16>(whf[ni], alf[mi], acc[ni][mi]);
+                    if constexpr (NPASS == 3) acc[ni][mi] = mma16<F16>(whf[ni], alf[mi], acc[ni][mi]);
                     acc[ni][mi] = mma16<F16>(whf[ni], ahf[mi], acc[ni][mi]);
                 }
         } else {
@@ -220,10 +224,10 @@ __device__ __forceinline__ void tile_regstage(const GemmParams& p, char* smem, i
     const int nt = kt_per_pass * p.npass;
 
     // (no lambdas / runtime-indexed arrays here: either leaves the prefetch registers in scratch)
-    // passes: lo*hi, hi*lo, then the dominant hi*hi
+    // passes: 0 = A_lo*W_hi, 1 = A_hi*W_lo, 2 = the dominant A_hi*W_hi; npass of them are run, the last ones
 #define GEMM_GLOAD(T)                                                                   \
     {                                                                                   \
-        const int pass_ = p.npass == 1 ? 2 : (T) / kt_per_pass;                         \
+        const int pass_ = 3 - p.npass + (T) / kt_per_pass; /* npass 1: hi*hi; 2: hi*lo, hi*hi; 3: all */ \
         const int k0_ = ((T) % kt_per_pass) * BK;                                       \
         const u16* Ab_ = (pass_ == 0 ? p.A_lo : p.A_hi) + k0_;                          \
         const u16* Wb_ = (pass_ == 1 ? p.W_lo : p.W_hi) + k0_;                          \
@@ -280,7 +284,7 @@ __device__ __forceinline__ void tile_regstage(const GemmParams& p, char* smem, i
 #undef GEMM_LSTORE
 }
 
-// MODE 0: register-staged fallback, 1: LDS-DMA bf16, 3: LDS-DMA bf16x3
+// MODE 0: register-staged fallback, 1: LDS-DMA one product, 2: LDS-DMA fp16x2 (A_hi*W_hi + A_hi*W_lo), 3: LDS-DMA bf16x3
 template <int MODE, int NSTAGE, bool F16>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m0, int n0, f32x4 (&acc)[4][4]) {
     if constexpr (MODE == 0) tile_regstage<F16>(p, smem, m0, n0, acc);
@@ -324,7 +328,8 @@ __device__ __forceinline__ float gelu_lut(float x, const float2* tbl) {
 }
 
 // epilogue for 4 consecutive output columns n..n+3 of row m: bias, activation, residual, stores
-__device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, float v0, float v1, float v2, float v3) {
+// `amax`: the thread's running max |value| of what it stores as planes (the kernel reports DIDI_FAULT_FP16_RANGE from it at the end)
+__device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, float v0, float v1, float v2, float v3, float& amax) {
     if (p.bias) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
         v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
@@ -350,9 +355,9 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
     if (p.C_f32) *reinterpret_cast<float4*>(p.C_f32 + o) = make_float4(v0, v1, v2, v3);
     if (p.C_hi) {
         const float v[4] = {v0, v1, v2, v3};
-        if (p.f16) raise_fault(p.fault, over_f16(v0) || over_f16(v1) || over_f16(v2) || over_f16(v3), DIDI_FAULT_FP16_RANGE);
+        amax = amax2(amax2(amax, v0, v1), v2, v3);
         uint2 h, l;
-        split4(v, h, l, p.f16, true);
+        split4(v, h, l, p.f16);
         *reinterpret_cast<uint2*>(p.C_hi + o) = h;
         if (p.C_lo) *reinterpret_cast<uint2*>(p.C_lo + o) = l;
     }
@@ -363,7 +368,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
 // `pre` != 0: the residual planes of these 8 columns were loaded ahead by the caller (rh_pre, rl_pre)
 // `bias8`: this tile's bias values for columns n..n+7, staged in LDS by the kernel's prologue (null: read p.bias from memory --
 // a dependent global load at the head of the epilogue cost the qkv launch 5 us per round, tools/epi_cost.py)
-__device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32x4 lo4, f32x4 hi4, const float2* gelu_tbl,
+__device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32x4 lo4, f32x4 hi4, const float2* gelu_tbl, float& amax,
                                           int pre = 0, uint4 rh_pre = uint4{0, 0, 0, 0}, uint4 rl_pre = uint4{0, 0, 0, 0},
                                           const float* bias8 = nullptr) {
     float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
@@ -406,20 +411,15 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32
         *reinterpret_cast<float4*>(p.C_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(p.C_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
     }
-    if (p.C_hi && p.f16) {
-        bool ovf = false;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ovf = ovf || over_f16(v[i]);
-        raise_fault(p.fault, ovf, DIDI_FAULT_FP16_RANGE);
-    }
+    amax = amax2(amax2(amax2(amax2(amax, v[0], v[1]), v[2], v[3]), v[4], v[5]), v[6], v[7]);
     if (p.C_hi && p.C_lo) {
         uint2 h0, l0, h1, l1;
-        split4(v, h0, l0, p.f16, true);
-        split4(v + 4, h1, l1, p.f16, true);
+        split4(v, h0, l0, p.f16);
+        split4(v + 4, h1, l1, p.f16);
         *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
         *reinterpret_cast<uint4*>(p.C_lo + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     } else if (p.C_hi) {  // one-product precisions keep no remainder of GEMM-only operands
-        const uint2 h0 = pack4_hi(v, p.f16, true), h1 = pack4_hi(v + 4, p.f16, true);
+        const uint2 h0 = pack4_hi(v, p.f16), h1 = pack4_hi(v + 4, p.f16);
         *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
     }
 }
@@ -441,11 +441,13 @@ __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_kernel(GemmPara
         p.K = min(p.k_split, p.K - k0);
         p.C_f32 += (size_t)blockIdx.y * p.M * p.ldc;
     }
+    if constexpr (F16) f16_saturate_mode();
     f32x4 acc[4][4];
     gemm_tile<MODE, NSTAGE, F16>(p, smem, m0, n0, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lg = lane >> 4;
+    float amax = 0.f;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wm * 64 + mi * 16 + lr;
@@ -454,9 +456,10 @@ __global__ void __launch_bounds__(256, NSTAGE <= 2 ? 2 : 1) gemm_kernel(GemmPara
         for (int ni = 0; ni < 4; ++ni) {
             const int n = n0 + wn * 64 + ni * 16 + lg * 4;
             if (n >= p.N) continue;
-            epilogue4(p, m, n, acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+            epilogue4(p, m, n, acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3], amax);
         }
     }
+    if constexpr (F16) raise_fault(p.fault, amax > DIDI_F16_MAX, DIDI_FAULT_FP16_RANGE);
 }
 
 // ------------------------------------------------------------------ big tile: 256(M) x 192(N), 8 waves
@@ -587,6 +590,8 @@ __global__ void __launch_bounds__(BigGeom<MT>::THREADS, 2) gemm_big_kernel(GemmP
             }
         }
     }
+    if constexpr (F16) f16_saturate_mode();
+    float amax = 0.f;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wm * 64 + mi * 16 + lr;
@@ -595,9 +600,10 @@ __global__ void __launch_bounds__(BigGeom<MT>::THREADS, 2) gemm_big_kernel(GemmP
         for (int ni = 0; ni < 6; ++ni) {
             const int n = n0 + wn * 96 + ni * 16 + lg * 4;
             if (n >= p.N) continue;
-            epilogue4(p, m, n, acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+            epilogue4(p, m, n, acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3], amax);
         }
     }
+    if constexpr (F16) raise_fault(p.fault, amax > DIDI_F16_MAX, DIDI_FAULT_FP16_RANGE);
 }
 
 // ------------------------------------------------------------------ big tile, staggered wave groups
@@ -622,8 +628,9 @@ __device__ __forceinline__ bool better(float v, int i, float bv, int bi);  // ar
 template <int NPASS, bool F16, bool LN, bool AMAX = false>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     using G = BigGeom<4>;
-    constexpr int BKK = NPASS == 3 ? 32 : 64;
+    constexpr int BKK = NPASS == 1 ? 64 : 32;
     constexpr int CPR = BKK * 2 / 16, RPI = 64 / CPR;   // 16-byte chunks per LDS row, rows per DMA piece
+    constexpr int NYP = NPASS == 2 ? 4 : 8;             // activation pieces per wave of group Y (fp16x2 stages no A_lo tile)
     constexpr int W_OFF = G::A_BYTES, LO_A = G::A_BYTES / 2, LO_W = 12288, STAGE = G::STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -645,10 +652,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     int qoff[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int q = w4 + 4 * (grp ? j : (j < 6 ? j : 5));
+        const int q = w4 + 4 * (grp ? (j < NYP ? j : NYP - 1) : (j < 6 ? j : 5));
         const u16* base;
         int row;
-        if (NPASS == 3) {
+        if (NPASS != 1) {
             if (grp) { base = q < 16 ? p.A_hi : p.A_lo; row = (q & 15) * RPI; }
             else { base = q < 12 ? p.W_hi : p.W_lo; row = (q < 12 ? q : q - 12) * RPI; }
         } else {
@@ -656,7 +663,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         }
         row += lane / CPR;
         const int slot = lane % CPR;
-        const int g = NPASS == 3 ? (slot ^ ((0 - (row >> 2)) & 3)) : (slot ^ (row & 7));
+        const int g = NPASS != 1 ? (slot ^ ((0 - (row >> 2)) & 3)) : (slot ^ (row & 7));
         // LDS weight row r' = 96*wn + 16*ni + rho holds output column 96*wn + 32*(ni>>1) + 8*(rho>>2) + 4*(ni&1) + (rho&3):
         // accumulator tiles 2k and 2k+1 then give every lane 8 CONSECUTIVE columns (epilogue8)
         const int wn_ = row / 96, rr_ = row % 96, ni_ = rr_ >> 4, rho_ = rr_ & 15;
@@ -671,11 +678,11 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         _Pragma("unroll") for (int j = 0; j < (N); ++j) glds16(src[j] + (T) * BKK, st_ + qoff[j]); \
     } while (0)
 
-    // fragments: NPASS 1: fw[ks*6 + ni], fa[ks*4 + mi]; NPASS 3: fw[ni] hi, fw[6 + ni] lo, fa[mi] hi, fa[4 + mi] lo
+    // fragments: NPASS 1: fw[ks*6 + ni], fa[ks*4 + mi]; NPASS 3: fw[ni] hi, fw[6 + ni] lo, fa[mi] hi, fa[4 + mi] lo (NPASS 2: no fa lo)
     bf16x8 fw[12], fa[8];
 #define PP_READ(ST)                                                                                        \
     do {                                                                                                   \
-        if constexpr (NPASS == 3) {                                                                        \
+        if constexpr (NPASS != 1) {                                                                        \
             _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                \
                 const int wo = swz64(wn * 96 + i * 16 + lr, lg);                                           \
                 fw[i] = *reinterpret_cast<const bf16x8*>((ST) + W_OFF + wo);                               \
@@ -684,7 +691,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
                 const int ao = swz64(wm * 64 + i * 16 + lr, lg);                                           \
                 fa[i] = *reinterpret_cast<const bf16x8*>((ST) + ao);                                       \
-                fa[4 + i] = *reinterpret_cast<const bf16x8*>((ST) + LO_A + ao);                            \
+                if constexpr (NPASS == 3) fa[4 + i] = *reinterpret_cast<const bf16x8*>((ST) + LO_A + ao);  \
             }                                                                                              \
         } else {                                                                                           \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                             \
@@ -698,12 +705,12 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     // PART 0: what runs in slot B1, PART 1: the rest, PART 2: everything
 #define PP_MFMA(PART)                                                                                      \
     do {                                                                                                   \
-        if constexpr (NPASS == 3) {                                                                        \
+        if constexpr (NPASS != 1) {                                                                        \
             _Pragma("unroll") for (int ni = ((PART) == 1 ? 2 : 0); ni < ((PART) == 0 ? 2 : 6); ++ni)       \
                 _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                         \
-                    acc[ni][mi] = mma16<false>(fw[6 + ni], fa[mi], acc[ni][mi]);                           \
-                    acc[ni][mi] = mma16<false>(fw[ni], fa[4 + mi], acc[ni][mi]);                           \
-                    acc[ni][mi] = mma16<false>(fw[ni], fa[mi], acc[ni][mi]);                               \
+                    acc[ni][mi] = mma16<F16>(fw[6 + ni], fa[mi], acc[ni][mi]);                             \
+                    if constexpr (NPASS == 3) acc[ni][mi] = mma16<F16>(fw[ni], fa[4 + mi], acc[ni][mi]);   \
+                    acc[ni][mi] = mma16<F16>(fw[ni], fa[mi], acc[ni][mi]);                                 \
                 }                                                                                          \
         } else {                                                                                           \
             _Pragma("unroll") for (int ni = ((PART) == 1 ? 4 : 0); ni < ((PART) == 0 ? 4 : 6); ++ni)       \
@@ -719,7 +726,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 
     // one-product GELU launches: the 8-KiB table rides behind the stages, one LDS-DMA piece per wave,
     // issued first so that every later counted wait covers it
-    const bool use_lut = NPASS == 1 && p.act == DIDI_ACT_GELU;
+    const bool use_lut = NPASS != 3 && p.act == DIDI_ACT_GELU;
     if (use_lut) glds16(reinterpret_cast<const u16*>(didi_gelu_table) + wave * 512 + lane * 8, smem + 2 * STAGE + wave * 1024);
     // the tile's 192 bias values ride along too (one 768-byte piece, wave 0): the epilogue then reads them from LDS instead of
     // opening with a dependent global load
@@ -738,9 +745,11 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         if (nt > 1) { PP_ISSUE(1, 1, 6); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-        PP_ISSUE(0, 0, 8);
-        if (nt > 1) { PP_ISSUE(1, 1, 8); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_ISSUE(0, 0, NYP);
+        if (nt > 1) {
+            PP_ISSUE(1, 1, NYP);
+            if constexpr (NYP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     if (grp == 0) {
@@ -776,8 +785,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();  // end of B1_i
             if (i + 2 < nt) {
-                PP_ISSUE(i + 2, i & 1, 8);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                PP_ISSUE(i + 2, i & 1, NYP);
+                if constexpr (NYP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -839,7 +848,9 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     // residual planes: all 12 loads of half a wave tile are issued before the first use (the fragment
     // registers are dead by now), instead of one exposed memory round trip per 8 columns
     const int pre = p.R_hi != nullptr && p.R_f32 == nullptr;
+    if constexpr (F16) f16_saturate_mode();
     if constexpr (!LN) {
+        float amax = 0.f;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             uint4 rh[2][3], rl[2][3];
@@ -864,11 +875,12 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const int n = n0 + wn * 96 + 32 * k + 8 * lg;
-                    if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi], gelu_tbl, pre, rh[mj][k], rl[mj][k], bias_lds + (n - n0));
-                    else if (n < p.N) epilogue4(p, m, n, acc[2 * k][mi][0], acc[2 * k][mi][1], acc[2 * k][mi][2], acc[2 * k][mi][3]);
+                    if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi], gelu_tbl, amax, pre, rh[mj][k], rl[mj][k], bias_lds + (n - n0));
+                    else if (n < p.N) epilogue4(p, m, n, acc[2 * k][mi][0], acc[2 * k][mi][1], acc[2 * k][mi][2], acc[2 * k][mi][3], amax);
                 }
             }
         }
+        if constexpr (F16) raise_fault(p.fault, p.C_hi != nullptr && amax > DIDI_F16_MAX, DIDI_FAULT_FP16_RANGE);
     } else {
         // ---- fused LayerNorm: the tiles_n (= 4) workgroups of a 256-row band each hold 192 of the 768 columns
         // of every row.  Each computes exact local row statistics (sum, M2 about its local mean), publishes them,
@@ -1043,12 +1055,26 @@ static int fill_operands(GemmParams& p, int precision, const u16* A_hi, const u1
         p.A_lo = A_lo; p.W_lo = W_lo;
         return DIDI_OK;
     }
+    if (precision == DIDI_PREC_FP16X3) {  // all three products on fp16 planes (~22 bits): the final rounding / logits of the fp16 modes
+        if (!A_lo || !W_lo) return DIDI_ERR_BAD_ARG;
+        p.npass = 3;
+        p.f16 = 1;
+        p.A_lo = A_lo; p.W_lo = W_lo;
+        return DIDI_OK;
+    }
+    if (precision == DIDI_PREC_FP16X2) {  // A_hi * (W_hi + W_lo) on fp16 planes: the weights enter exactly, the activations rounded
+        if (!W_lo) return DIDI_ERR_BAD_ARG;
+        p.npass = 2;
+        p.f16 = 1;
+        p.A_lo = A_hi; p.W_lo = W_lo;  // A_lo never read
+        return DIDI_OK;
+    }
     return DIDI_ERR_BAD_ARG;
 }
 
 // 0 = register-staged fallback, else the LDS-DMA variant for the precision
 static int pick_mode(const GemmParams& p) {
-    if (p.npass == 3) return p.K % 32 == 0 ? 3 : 0;
+    if (p.npass != 1) return p.K % 32 == 0 ? p.npass : 0;
     return p.K % 64 == 0 ? 1 : 0;
 }
 
@@ -1086,6 +1112,8 @@ static const DeviceInfo* device_info() {
         ok = ok && opt_in_pp<3, false, false, false>() && opt_in_pp<1, false, false, false>() && opt_in_pp<1, true, false, false>();
         ok = ok && opt_in_pp<3, false, true, false>() && opt_in_pp<1, false, true, false>() && opt_in_pp<1, true, true, false>();
         ok = ok && opt_in_pp<3, false, false, true>() && opt_in_pp<1, false, false, true>() && opt_in_pp<1, true, false, true>();
+        ok = ok && opt_in_pp<2, true, false, false>() && opt_in_pp<2, true, true, false>() && opt_in_pp<2, true, false, true>();
+        ok = ok && opt_in_pp<3, true, false, false>() && opt_in_pp<3, true, false, true>();
         int c = 0;
         ok = ok && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0;
         d.ncu = c;
@@ -1128,31 +1156,37 @@ extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
     const int mode = pick_mode(p);
     const int big_tiles_n = cdiv(a->N, BBN);
     const int big_min_m = didi_opt(DIDI_OPT_BIG_MIN_M);  // tuning knob
+    const bool mt4 = gemm_big_mt() == 4;
+    const bool wide_ok = a->ldc % 8 == 0 && al16(a->C_hi) && al16(a->C_lo) && al16(a->R_hi) && al16(a->R_lo) &&
+                         (!(a->R_f32 || a->R_hi) || a->ldr % 8 == 0);
     const bool big = mode != 0 && gemm_big_enabled() && a->M >= big_min_m && a->N >= BBN &&
-                     (long)big_tiles_n * BBN * 100 <= (long)a->N * 115;  // <= 15 % padded columns
+                     (long)big_tiles_n * BBN * 100 <= (long)a->N * 115 &&  // <= 15 % padded columns
+                     (!(mode == 2 || (mode == 3 && p.f16)) || (mt4 && wide_ok && gemm_pp_enabled()));  // fp16x2 / fp16x3: staggered kernel only
     if (big) {
         if (!allow_big_lds()) return DIDI_ERR_LAUNCH;
         p.tiles_n = big_tiles_n;
-        const bool mt4 = gemm_big_mt() == 4;
-        const bool wide_ok = a->ldc % 8 == 0 && al16(a->C_hi) && al16(a->C_lo) && al16(a->R_hi) && al16(a->R_lo) &&
-                             (!(a->R_f32 || a->R_hi) || a->ldr % 8 == 0);
         if (mt4 && wide_ok && gemm_pp_enabled()) {
             p.tiles_m = cdiv(p.M, 256);
             const int grid = p.tiles_m * p.tiles_n;
             const size_t lds = PP_LDS_BYTES;  // + GELU table
-            if (mode == 3) gemm_pp_kernel<3, false, false><<<grid, 512, lds, st>>>(p);
+            if (mode == 3 && p.f16) gemm_pp_kernel<3, true, false><<<grid, 512, lds, st>>>(p);
+            else if (mode == 3) gemm_pp_kernel<3, false, false><<<grid, 512, lds, st>>>(p);
+            else if (mode == 2) gemm_pp_kernel<2, true, false><<<grid, 512, lds, st>>>(p);
             else if (p.f16) gemm_pp_kernel<1, true, false><<<grid, 512, lds, st>>>(p);
             else gemm_pp_kernel<1, false, false><<<grid, 512, lds, st>>>(p);
             DIDI_LAUNCH_CHECK();
             return DIDI_OK;
         }
+        if (mode == 2 || (mode == 3 && p.f16)) return DIDI_ERR_UNSUPPORTED;  // excluded by `big` above
         if (mode == 3) { if (mt4) launch_big<3, 4, false>(p, st); else launch_big<3, 2, false>(p, st); }
         else if (p.f16) { if (mt4) launch_big<1, 4, true>(p, st); else launch_big<1, 2, true>(p, st); }
         else { if (mt4) launch_big<1, 4, false>(p, st); else launch_big<1, 2, false>(p, st); }
     } else {
         p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
         const int grid = p.tiles_m * p.tiles_n;
-        if (mode == 3) gemm_kernel<3, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
+        if (mode == 3 && p.f16) gemm_kernel<3, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
+        else if (mode == 3) gemm_kernel<3, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
+        else if (mode == 2) gemm_kernel<2, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
         else if (mode == 1 && p.f16) gemm_kernel<1, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
         else if (mode == 1) gemm_kernel<1, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
         else if (p.f16) gemm_kernel<0, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
@@ -1172,7 +1206,7 @@ static int small_splits(int M, int N, int K, int precision) {
     if (M <= 0 || M >= max_m || N % 4 != 0 || N > 3072) return 0;
     const int unit = 128;  // K columns per split are a multiple of this (two one-product K-tiles, four bf16x3 ones)
     if (K % unit != 0 || K < 2 * unit) return 0;
-    if (precision != DIDI_PREC_BF16 && precision != DIDI_PREC_FP16 && precision != DIDI_PREC_BF16X3) return 0;
+    if (precision != DIDI_PREC_BF16 && precision != DIDI_PREC_FP16 && precision != DIDI_PREC_BF16X3 && precision != DIDI_PREC_FP16X2 && precision != DIDI_PREC_FP16X3) return 0;
     const int wgs = cdiv(M, BM) * cdiv(N, BN);
     int ks = std::min(cdiv(256, wgs), K / unit);
     if (ks < 2) return 0;
@@ -1237,15 +1271,16 @@ __device__ __forceinline__ void rows_store(const RowsParams& p, int m, int c, co
     const size_t o = (size_t)m * p.N + (size_t)c * 4;
     if (p.y_f32) *reinterpret_cast<float4*>(p.y_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
     if (p.y_hi) {
-        if (p.f16) raise_fault(p.fault, over_f16(y[0]) || over_f16(y[1]) || over_f16(y[2]) || over_f16(y[3]), DIDI_FAULT_FP16_RANGE);
+        if (p.f16) raise_fault(p.fault, amax2(amax2(0.f, y[0], y[1]), y[2], y[3]) > DIDI_F16_MAX, DIDI_FAULT_FP16_RANGE);
         uint2 h, l;
-        split4(y, h, l, p.f16, true);
+        split4(y, h, l, p.f16);
         *reinterpret_cast<uint2*>(p.y_hi + o) = h;
         if (p.y_lo) *reinterpret_cast<uint2*>(p.y_lo + o) = l;
     }
 }
 
 __global__ void __launch_bounds__(256) splitk_sum_kernel(RowsParams p) {
+    if (p.f16) f16_saturate_mode();
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int nc = p.N / 4;
     if (i >= (size_t)p.M * nc) return;
@@ -1266,6 +1301,7 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {  // red: 4 
 template <int CH>
 __global__ void __launch_bounds__(256) splitk_ln_kernel(RowsParams p) {
     __shared__ float red[4];
+    if (p.f16) f16_saturate_mode();
     const int m = blockIdx.x, nc = p.N / 4;
     float v[CH][4];
     float s = 0.f;
@@ -1321,7 +1357,9 @@ extern "C" int didi_gemm_small(const didi_gemm_args* a, const float* gamma, cons
     p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
     hipStream_t st = as_stream(stream);
     const dim3 grid(p.tiles_m * p.tiles_n, ks);
-    if (p.npass == 3) gemm_kernel<3, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
+    if (p.npass == 3 && p.f16) gemm_kernel<3, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
+    else if (p.npass == 3) gemm_kernel<3, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
+    else if (p.npass == 2) gemm_kernel<2, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
     else if (p.f16) gemm_kernel<1, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
     else gemm_kernel<1, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
     DIDI_LAUNCH_CHECK();
@@ -1330,7 +1368,7 @@ extern "C" int didi_gemm_small(const didi_gemm_args* a, const float* gamma, cons
     r.bias = a->bias; r.act = a->act;
     r.r_hi = a->R_hi; r.r_lo = a->R_lo; r.r_f32 = a->R_f32; r.ldr = a->ldr;
     r.gamma = gamma; r.beta = beta; r.eps = eps;
-    r.y_hi = a->C_hi; r.y_lo = a->C_lo; r.y_f32 = a->C_f32; r.f16 = a->precision == DIDI_PREC_FP16;
+    r.y_hi = a->C_hi; r.y_lo = a->C_lo; r.y_f32 = a->C_f32; r.f16 = p.f16;
     r.fault = a->fault;
     if (!gamma) splitk_sum_kernel<<<cdiv((long)a->M * (a->N / 4), 256), 256, 0, st>>>(r);
     else if (a->N <= 1024) splitk_ln_kernel<1><<<a->M, 256, 0, st>>>(r);
@@ -1342,7 +1380,7 @@ extern "C" int didi_gemm_small(const didi_gemm_args* a, const float* gamma, cons
 
 // ------------------------------------------------------------------ output projection + residual + LayerNorm
 extern "C" int didi_gemm_ln_supported(int M, int N, int K, int precision) {
-    const bool prec_ok = precision == DIDI_PREC_BF16 || precision == DIDI_PREC_FP16 || precision == DIDI_PREC_BF16X3;
+    const bool prec_ok = precision == DIDI_PREC_BF16 || precision == DIDI_PREC_FP16 || precision == DIDI_PREC_BF16X3 || precision == DIDI_PREC_FP16X2;
     return prec_ok && M >= 2048 && N == 4 * BBN && K % 64 == 0 && K >= 128;
 }
 
@@ -1387,6 +1425,7 @@ extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const f
         p.ln_stats = reinterpret_cast<unsigned long long*>(stats) + (size_t)b0 * 4 * 512;
         const int grid = nb * 4;
         if (p.npass == 3) gemm_pp_kernel<3, false, true><<<grid, 512, lds, st>>>(p);
+        else if (p.npass == 2) gemm_pp_kernel<2, true, true><<<grid, 512, lds, st>>>(p);
         else if (p.f16) gemm_pp_kernel<1, true, true><<<grid, 512, lds, st>>>(p);
         else gemm_pp_kernel<1, false, true><<<grid, 512, lds, st>>>(p);
         DIDI_LAUNCH_CHECK();
@@ -1613,7 +1652,9 @@ int didi_round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const u
         p.partial = reinterpret_cast<float2*>(partial);
         const int grid = p.tiles_m * p.tiles_n;
         const size_t lds = PP_LDS_BYTES;
-        if (p.npass == 3) gemm_pp_kernel<3, false, false, true><<<grid, 512, lds, st>>>(p);
+        if (p.npass == 3 && p.f16) gemm_pp_kernel<3, true, false, true><<<grid, 512, lds, st>>>(p);
+        else if (p.npass == 3) gemm_pp_kernel<3, false, false, true><<<grid, 512, lds, st>>>(p);
+        else if (p.npass == 2) gemm_pp_kernel<2, true, false, true><<<grid, 512, lds, st>>>(p);
         else if (p.f16) gemm_pp_kernel<1, true, false, true><<<grid, 512, lds, st>>>(p);
         else gemm_pp_kernel<1, false, false, true><<<grid, 512, lds, st>>>(p);
         DIDI_LAUNCH_CHECK();
@@ -1633,7 +1674,11 @@ int didi_round_impl(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const u
     const int grid = p.tiles_m * p.nchunks;
 #define DIDI_ROUND_LAUNCH(CE_)                                                                           \
     switch (pick_mode(p)) {                                                                              \
-        case 3: gemm_argmax_kernel<3, 2, false, CE_><<<grid, 256, SMEM_BYTES, st>>>(p); break;           \
+        case 3:                                                                                          \
+            if (p.f16) gemm_argmax_kernel<3, 2, true, CE_><<<grid, 256, SMEM_BYTES, st>>>(p);            \
+            else gemm_argmax_kernel<3, 2, false, CE_><<<grid, 256, SMEM_BYTES, st>>>(p);                 \
+            break;                                                                                       \
+        case 2: gemm_argmax_kernel<2, 2, true, CE_><<<grid, 256, SMEM_BYTES, st>>>(p); break;            \
         case 1:                                                                                          \
             if (p.f16) gemm_argmax_kernel<1, 2, true, CE_><<<grid, 256, SMEM_BYTES, st>>>(p);            \
             else gemm_argmax_kernel<1, 2, false, CE_><<<grid, 256, SMEM_BYTES, st>>>(p);                 \

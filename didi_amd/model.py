@@ -59,14 +59,14 @@ class _Classifier:
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
         hi, lo = ops.split(x2, dtype=self.planes.hi.dtype)
-        _, _, y = self.planes(hi, lo, self._owner.precision, out_f32=True, out_planes=False)
+        _, _, y = self.planes(hi, lo, self._owner.round_precision, out_f32=True, out_planes=False)
         return y.reshape(*lead, -1)
 
 
 class DiDiSampler:
     def __init__(self, state_dict, cfg: DiDiConfig, device="cuda", precision="bf16x3"):
-        if precision not in ops.PRECISIONS:
-            raise ValueError(f"precision must be one of {sorted(ops.PRECISIONS)}")
+        if precision not in ("bf16", "fp16", "fp16x2", "bf16x3"):
+            raise ValueError("precision must be one of bf16, fp16, fp16x2, bf16x3")
         self.cfg, self.device, self.precision = cfg, torch.device(device), precision
         sd = state_dict
         dev = self.device
@@ -288,6 +288,17 @@ class DiDiSampler:
     @property
     def prec(self):
         return ops.PRECISIONS[self.precision]
+
+    @property
+    def round_precision(self):
+        """Precision of the classifier GEMM after the loop (rounding argmax, logits, cross-entropy): the fp16x2 mode spends
+        all three products there (once per batch), as the engine's final rounding does."""
+        return "fp16x3" if self.precision == "fp16x2" else self.precision
+
+    def round_operands(self, x0_hi, x0_lo):
+        """(x_hi, x_lo or None, precision) for ops.round_argmax / ops.round_ce on x0 planes."""
+        rp = self.round_precision
+        return x0_hi, (x0_lo if rp in ("bf16x3", "fp16x3") else None), rp
 
     def buffers(self, B, S, Cn):
         key = (B, S, Cn)

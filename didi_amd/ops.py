@@ -11,7 +11,8 @@ import torch
 from . import _lib
 from ._lib import lib
 
-PRECISIONS = {"bf16": _lib.PREC_BF16, "fp16": _lib.PREC_FP16, "bf16x3": _lib.PREC_BF16X3}
+PRECISIONS = {"bf16": _lib.PREC_BF16, "fp16": _lib.PREC_FP16, "bf16x3": _lib.PREC_BF16X3, "fp16x2": _lib.PREC_FP16X2,
+              "fp16x3": _lib.PREC_FP16X3}  # fp16x3: rounding / logits GEMMs only (three products on fp16 planes)
 ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "gelu": _lib.ACT_GELU, "tanh": _lib.ACT_TANH, "relu": _lib.ACT_RELU,
         "gelu_new": _lib.ACT_GELU_NEW}
 
@@ -22,7 +23,7 @@ def _prec(p):
 
 def plane_dtype(precision):
     """torch dtype of the split planes a precision works on (fp16 planes for "fp16", bf16 otherwise)."""
-    return torch.float16 if _prec(precision) == _lib.PREC_FP16 else torch.bfloat16
+    return torch.float16 if _prec(precision) in (_lib.PREC_FP16, _lib.PREC_FP16X2, _lib.PREC_FP16X3) else torch.bfloat16
 
 
 def _fmt(dtype):

@@ -110,8 +110,8 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
         _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp)
         if want_ids:
             x0_hi, x0_lo = ops.split(b["x0"].view(B * S, H), dtype=model._pd)
-            ids = ops.round_argmax(x0_hi, x0_lo if model.precision == "bf16x3" else None, model._cls.hi, model._cls.lo,
-                                   model.precision).view(B, S)
+            xh, xl, rp = model.round_operands(x0_hi, x0_lo)
+            ids = ops.round_argmax(xh, xl, model._cls.hi, model._cls.lo, rp).view(B, S)
     else:
         xt_trace = torch.empty((n_calls, B, S, H), dtype=torch.float32, device=dev) if trace is not None else None
         ids = torch.empty((B, S), dtype=torch.int64, device=dev) if want_ids or clamp else None

@@ -39,4 +39,5 @@ def token_ce(model, x0, target_ids):
     """ids [M], nll [M] of ``classifier(x0)`` against ``target_ids``, logits never materialised."""
     H = x0.shape[-1]
     hi, lo = ops.split(x0.reshape(-1, H).contiguous(), dtype=model._pd)
-    return ops.round_ce(hi, lo if model.precision == "bf16x3" else None, model._cls.hi, model._cls.lo, target_ids, model.precision)
+    xh, xl, rp = model.round_operands(hi, lo)
+    return ops.round_ce(xh, xl, model._cls.hi, model._cls.lo, target_ids, rp)

@@ -50,7 +50,8 @@ enum {
  *   DIDI_FAULT_LN_EXCHANGE  a workgroup of didi_gemm_ln gave up waiting for its band mates' row statistics (the launch
  *                           was not co-resident: another kernel or a CU mask held CUs).  The rows it owned are NaN.
  *   DIDI_FAULT_FP16_RANGE   a GEMM epilogue in DIDI_PREC_FP16 produced |value| > 65504 for an fp16 plane.  The planes
- *                           hold the value SATURATED to +-65504 (never inf); results downstream are not to be trusted
+ *                           hold the value SATURATED: hi = +-65504, lo = the saturated remainder (conversions run in the hardware's FP16_OVFL mode: no inf is created;
+ *                           an inf / NaN already in the data stays); results downstream are not to be trusted
  *                           at fp16 precision: rerun in DIDI_PREC_BF16X3 (bf16 planes have fp32's range).
  * No reference counterpart: the reference computes in fp32 on one stream. */
 enum { DIDI_FAULT_LN_EXCHANGE = 1, DIDI_FAULT_FP16_RANGE = 2 };
@@ -80,7 +81,16 @@ int didi_get_option(int key, int* value);
  * planes -- 8x finer operand rounding than BF16 at the same MFMA cost; lo planes are only read where
  * a value is re-joined (residual adds).  Planes written by a call take the format of its precision
  * (fp16 for DIDI_PREC_FP16, bf16 otherwise). */
-enum { DIDI_PREC_BF16 = 1, DIDI_PREC_FP16 = 2, DIDI_PREC_BF16X3 = 3 };
+enum { DIDI_PREC_BF16 = 1, DIDI_PREC_FP16 = 2, DIDI_PREC_BF16X3 = 3,
+       /* FP16X2: fp16 planes, TWO products A_hi*W_hi + A_hi*W_lo: the weights enter with their remainder (~22 bits), the
+        * activations as one fp16 plane.  Rounding the weights is the error that adds up coherently over the calls of a sampling
+        * loop (the same perturbation of the model at every call); the activations' rounding does not.
+        * Activation planes, attention and epilogues as DIDI_PREC_FP16; W_lo required, A_lo never read. */
+       DIDI_PREC_FP16X2 = 4,
+       /* FP16X3: fp16 planes, all three products (A_hi*W_hi + A_hi*W_lo + A_lo*W_hi, ~22 bits): accepted by didi_gemm_bf16,
+        * didi_gemm_small, didi_round_argmax and didi_round_ce.  The engine uses it for the FINAL rounding of an FP16X2 loop
+        * (once per batch) and the Python side for materialised logits; the decoder loop itself does not take it. */
+       DIDI_PREC_FP16X3 = 5 };
 enum { DIDI_FMT_BF16 = 0, DIDI_FMT_FP16 = 1 }; /* element format of split planes */
 
 /* ABI version / error text (no reference counterpart). */
@@ -166,7 +176,7 @@ int didi_layernorm(const float* x, const float* gamma, const float* beta, float 
  * contiguous), pre-split into planes.  Replaces every nn.Linear on the path:
  * Bert query/key/value/dense (HF:models/bert/modeling_bert.py:175-177,244,253-254,290,335,348),
  * the adapter (src/diffusion/model.py:123), `classifier` (src/sampling.py:64,82).
- *   precision : DIDI_PREC_BF16 / DIDI_PREC_FP16 (A_hi*W_hi) or DIDI_PREC_BF16X3 (+ A_hi*W_lo + A_lo*W_hi)
+ *   precision : DIDI_PREC_BF16 / DIDI_PREC_FP16 (A_hi*W_hi), DIDI_PREC_FP16X2 (+ A_hi*W_lo) or DIDI_PREC_BF16X3 (+ A_hi*W_lo + A_lo*W_hi)
  *   epilogue  : v = acc (+ bias[n]) ; v = act(v) ; v += residual[m,n]
  *               act: 0 none, 1 exact-erf GELU (hidden_act="gelu"; evaluated to <= 1.5e-7 in BF16X3 and to
  *               <= 3.4e-6 absolute -- a table -- in the one-product precisions, whose outputs are rounded

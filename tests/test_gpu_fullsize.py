@@ -2,8 +2,10 @@
 
 The fixtures from the reference pin the oracle on small models (tests/test_oracle_golden.py); here the oracle is the
 reference for the cfg2-sized model (12 x 768 decoder, 2 x 1280 encoder, V = 8008 / 50 000) that bench.py times:
-  * token-id agreement >= 99.9 % and every denoiser input x_t within rel-L2 1e-3 (fp16) / 1e-4 (bf16x3) over a whole
-    T = 2000, step_freq = 10 loop (201 denoiser calls), ddpm and euler (= the "DDIM 200-step" of BASELINE configs[2]);
+  * token-id agreement >= 99.9 % and every denoiser input x_t within rel-L2 1e-3 (fp16x2, bench.py's default) / 1e-4 (bf16x3)
+    over a whole T = 2000, step_freq = 10 loop (201 denoiser calls), ddpm and euler (= the "DDIM 200-step" of BASELINE
+    configs[2]).  The one-product fp16 mode is run too and REPORTED: round 2 found that it misses both bars in ddpm at this
+    size (3 of 1024 ids, x_t 1.8e-3), so it only has to stay within 3e-3 / 99 % here and is not what bench.py times;
   * one denoiser call + rounding at the exact bench shape B = 256, S = C = 64 (M = 16 384 rows: 64 row bands = 256
     workgroups = every CU in one didi_gemm_ln launch), finite everywhere, no device fault;
   * BASELINE configs[3]'s shape: V = 50 000, S = C = 84, B = 1024 (M = 86 016) with the per-step clamp extension.
@@ -22,6 +24,15 @@ pytestmark = pytest.mark.gpu
 def rel_l2(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+class TickNoise(ListNoise):
+    """ListNoise that prints a heartbeat: the CPU oracle's 201-call loop takes minutes and a silent GPU job reads as hung."""
+
+    def __call__(self, shape):
+        if self.i % 20 == 0:
+            print(f"  oracle draw {self.i}/{len(self.draws)}", flush=True)
+        return super().__call__(shape)
 
 
 def _ctx(ids, mask):
@@ -53,14 +64,14 @@ def test_cfg2_size_loop_ids_and_xt_vs_oracle(mode):
     t0 = time.time()
     want_trace = []
     want = oracle_sample(Context(ids[:Bo], mask[:Bo]), OracleDiDi(sd, config_to_oracle_config(cfg)), mode, f, max_len=S,
-                         raw_output=True, noise_source=ListNoise([noise[i, :Bo] for i in range(n_draws)]), trace=want_trace)
+                         raw_output=True, noise_source=TickNoise([noise[i, :Bo] for i in range(n_draws)]), trace=want_trace)
     want_ids = want.argmax(-1)
     top2 = want.topk(2, -1).values
     print(f"\n[cfg2 {mode} f={f}] oracle: {n_calls} calls x {Bo} dialogs in {time.time() - t0:.0f} s; "
           f"median top-2 logit gap {float((top2[..., 0] - top2[..., 1]).median()):.3f}")
     assert len(want_trace) == n_calls
     noise_dev = noise.cuda()
-    for precision, xt_bar in (("bf16x3", 1e-4), ("fp16", 1e-3)):
+    for precision, xt_bar, id_bar in (("bf16x3", 1e-4, 0.999), ("fp16x2", 1e-3, 0.999), ("fp16", 3e-3, 0.99)):
         model = DiDiSampler(sd, cfg, device="cuda", precision=precision)
         trace = []
         got, _ = sample(_ctx(ids, mask), model, mode, f, max_len=S, noise=noise_dev, return_ids=True, trace=trace)
@@ -70,13 +81,13 @@ def test_cfg2_size_loop_ids_and_xt_vs_oracle(mode):
         print(f"[cfg2 {mode} f={f} {precision}] ids differ on {flips} of {want_ids.numel()} positions "
               f"({100 - 100.0 * flips / want_ids.numel():.3f} % agree); max x_t rel-L2 over {n_calls} calls {worst:.3e}")
         assert worst <= xt_bar
-        assert 1.0 - flips / want_ids.numel() >= 0.999
+        assert 1.0 - flips / want_ids.numel() >= id_bar
         del model, trace
 
 
 def test_bench_shape_single_call_full_chip():
-    """B = 256, S = C = 64 (bench.py's shape): one denoiser call + rounding in fp16.  Every output finite, no device fault, and
-    the first 4 dialogs agree with the oracle; then the same through bf16x3 at 1e-4."""
+    """B = 256, S = C = 64 (bench.py's shape): one denoiser call + rounding in fp16x2 (bench.py's default), fp16 and bf16x3.
+    Every output finite, no device fault, and the first 4 dialogs agree with the oracle."""
     from didi_amd import ops
     from didi_amd.config import DiDiConfig
     from didi_amd.model import DiDiSampler
@@ -93,7 +104,7 @@ def test_bench_shape_single_call_full_chip():
     oracle = OracleDiDi(sd, config_to_oracle_config(cfg))
     want, _ = oracle(encoder_input_ids=ids[:Bo], encoder_attention_mask=mask[:Bo], decoder_inputs_embeds=x_t[:Bo], time_ids=tids[:Bo])
     want_ids = oracle.classifier(want).argmax(-1)
-    for precision, bar in (("fp16", 2e-3), ("bf16x3", 1e-4)):
+    for precision, bar in (("fp16x2", 1e-3), ("fp16", 2e-3), ("bf16x3", 1e-4)):
         model = DiDiSampler(sd, cfg, device="cuda", precision=precision)
         out, _ = model(encoder_input_ids=ids.cuda(), encoder_attention_mask=mask.cuda(), decoder_inputs_embeds=x_t.cuda(),
                        time_ids=tids.cuda())
@@ -129,7 +140,7 @@ def test_config3_shape_large_vocab_clamp():
     want_trace = []
     want = oracle_sample(Context(ids[:Bo], mask[:Bo]), OracleDiDi(sd, config_to_oracle_config(cfg)), "ddpm", 1, max_len=S,
                          raw_output=True, noise_source=ListNoise([noise[0, :Bo], noise[1, :Bo]]), trace=want_trace, clamp=True)
-    model = DiDiSampler(sd, cfg, device="cuda", precision="fp16")
+    model = DiDiSampler(sd, cfg, device="cuda", precision="fp16x2")
     trace = []
     got, lengths = sample(_ctx(ids, mask), model, "ddpm", 1, max_len=S, noise=noise.cuda(), return_ids=True, trace=trace, clamp=True)
     model.check_fault("config3 shape")
@@ -138,7 +149,7 @@ def test_config3_shape_large_vocab_clamp():
     # call 1's input depends on call 0's clamped ids: a differing id there moves x_t, so report both and bound the first call
     e0 = rel_l2(trace[0][:Bo], want_trace[0])
     e1 = rel_l2(trace[1][:Bo], want_trace[1])
-    print(f"\n[config3 shape fp16, clamp] id match {match:.4f} on {Bo * S} positions; x_t rel-L2 call 0 {e0:.3e}, call 1 {e1:.3e}")
+    print(f"\n[config3 shape fp16x2, clamp] id match {match:.4f} on {Bo * S} positions; x_t rel-L2 call 0 {e0:.3e}, call 1 {e1:.3e}")
     assert e0 <= 1e-6  # the initial noise, scaled
     assert match >= 0.97  # random-init weights at V = 50 000: top-2 gaps are small, a clamp flip feeds back (parity unpinned by the reference)
     top_share = got.flatten().bincount(minlength=cfg.vocab).max().item() / got.numel()
@@ -167,7 +178,7 @@ def test_id_agreement_config1_2208_positions():
     want = oracle_sample(Context(ids, mask), OracleDiDi(sd, config_to_oracle_config(cfg)), "ddpm", 1, raw_output=True,
                          noise_source=ListNoise(draws), trace=trace).argmax(-1)
     n_calls = len(trace)
-    for precision, bar in (("bf16x3", 0.999), ("fp16", 0.999), ("bf16", 0.97)):
+    for precision, bar in (("bf16x3", 0.999), ("fp16x2", 0.999), ("fp16", 0.999), ("bf16", 0.97)):
         model = DiDiSampler(sd, cfg, device="cuda", precision=precision)
         tr = []
         got, _ = sample(_ctx(ids, mask), model, "ddpm", 1, noise=torch.stack(draws[:n_calls]), return_ids=True, trace=tr)

@@ -27,8 +27,18 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-PD = {"bf16": torch.bfloat16, "fp16": torch.float16, "bf16x3": torch.bfloat16}  # plane dtype per precision
-ALL_PREC = ["bf16", "fp16", "bf16x3"]
+PD = {"bf16": torch.bfloat16, "fp16": torch.float16, "bf16x3": torch.bfloat16, "fp16x2": torch.float16}  # plane dtype per precision
+ALL_PREC = ["bf16", "fp16", "bf16x3", "fp16x2"]
+
+
+def ref_operands(precision, a, w, a_hi, w_hi, w_lo):
+    """The operands a precision multiplies, as fp32 CPU tensors: one product = the hi planes; fp16x2 = A_hi x (W_hi + W_lo);
+    bf16x3 = the un-rounded values (its split carries ~16 bits, the lo*lo term is dropped: tolerance 3e-5)."""
+    if precision == "bf16x3":
+        return a, w
+    if precision == "fp16x2":
+        return a_hi.cpu().float(), (w_hi.float() + w_lo.float()).cpu()
+    return a_hi.cpu().float(), w_hi.cpu().float()
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -192,12 +202,8 @@ def test_gemm_plain(ops, M, N, K, precision):
     a_hi, a_lo = ops.split(a.cuda(), dtype=PD[precision])
     w_hi, w_lo = ops.split(w.cuda(), dtype=PD[precision])
     c_hi, c_lo, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), precision=precision, out_f32=True)
-    if precision != "bf16x3":
-        want = _gemm_ref(a_hi.cpu().float(), w_hi.cpu().float(), bias, None, None)
-        tol = 2e-5
-    else:
-        want = _gemm_ref(a, w, bias, None, None)
-        tol = 3e-5
+    want = _gemm_ref(*ref_operands(precision, a, w, a_hi, w_hi, w_lo), bias, None, None)
+    tol = 3e-5 if precision == "bf16x3" else 2e-5
     assert rel_l2(c, want) <= tol, rel_l2(c, want)
     assert (c.cpu().double() - want).abs().max().item() <= 50 * tol * want.abs().max().item()
     assert rel_l2(ops.join(c_hi, c_lo), c) <= 2e-5
@@ -245,7 +251,7 @@ def test_gemm_small_batch_form(ops, M, N, K, precision, ln):
     small = (g.cuda(), b.cuda(), 1e-12) if ln else ()
     c_hi, c_lo, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), act=act, precision=precision, residual_planes=rp,
                              out_f32=True, small=small)
-    ar, wr = (ops.join(a_hi, a_lo).cpu(), ops.join(w_hi, w_lo).cpu()) if x3 else (a_hi.cpu().float(), w_hi.cpu().float())
+    ar, wr = (ops.join(a_hi, a_lo).cpu(), ops.join(w_hi, w_lo).cpu()) if x3 else ref_operands(precision, a, w, a_hi, w_hi, w_lo)
     want = _gemm_ref(ar, wr, bias, act, ops.join(*rp).cpu())
     if ln:
         want = torch.nn.functional.layer_norm(want, (N,), g.double(), b.double(), 1e-12)
@@ -276,7 +282,7 @@ def test_gemm_big_tile(ops, M, N, K, precision):
     w_hi, w_lo = ops.split(w.cuda(), dtype=PD[precision])
     rp = ops.split(r.cuda(), dtype=PD[precision])
     x3 = precision == "bf16x3"
-    ar, wr = (a, w) if x3 else (a_hi.cpu().float(), w_hi.cpu().float())
+    ar, wr = ref_operands(precision, a, w, a_hi, w_hi, w_lo)
     tol = 3e-5 if x3 else 2e-5
     c_hi, c_lo, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), precision=precision, out_f32=True)
     want = _gemm_ref(ar, wr, bias, None, None)
@@ -304,7 +310,7 @@ def test_gemm_ln_fused(ops, M, K, precision):
     rp = ops.split(r.cuda(), dtype=pd)
     r_used = ops.join(*rp).cpu()
     y_hi, y_lo, y = ops.gemm_ln(a_hi, a_lo, w_hi, w_lo, bias.cuda(), rp, g.cuda(), b.cuda(), 1e-12, precision=precision, f32=True)
-    ar, wr = (a, w) if x3 else (a_hi.cpu().float(), w_hi.cpu().float())
+    ar, wr = ref_operands(precision, a, w, a_hi, w_hi, w_lo)
     want = torch.nn.functional.layer_norm(_gemm_ref(ar, wr, bias, None, r_used), (N,), g.double(), b.double(), 1e-12)
     assert rel_l2(y, want) <= 5e-6, rel_l2(y, want)  # measured 2.5e-6 (bf16x3: dropped lo*lo term), 3e-7 (one product)
     assert (y.cpu().double() - want).abs().max().item() <= 1e-3
@@ -313,6 +319,31 @@ def test_gemm_ln_fused(ops, M, K, precision):
     h_hi, h_lo = rp[0].clone(), rp[1].clone()
     ops.gemm_ln(a_hi, a_lo, w_hi, w_lo, bias.cuda(), (h_hi, h_lo), g.cuda(), b.cuda(), 1e-12, precision=precision, out=(h_hi, h_lo))
     assert torch.equal(h_hi, y_hi) and torch.equal(h_lo, y_lo)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (2304, 8008, 768), (63, 768, 768)])
+def test_gemm_and_rounding_fp16x3(ops, M, N, K):
+    """DIDI_PREC_FP16X3 (all three products on fp16 planes, ~22 bits; the final rounding / logits of the fp16x2 mode): 128x128 tile,
+    256x192 tile and the split-K small-batch form against fp64 on the UN-rounded operands at 5e-6; rounding ids exact where the
+    top-2 gap is not a near-tie; LayerNorm-fused launches do not take this precision."""
+    from didi_amd._lib import lib
+
+    a, w, bias = rnd(M, K, seed=61), rnd(N, K, seed=62, scale=0.05), rnd(N, seed=63)
+    a_hi, a_lo = ops.split(a.cuda(), dtype=torch.float16)
+    w_hi, w_lo = ops.split(w.cuda(), dtype=torch.float16)
+    want = _gemm_ref(a, w, bias, None, None)
+    c_hi, c_lo, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), precision="fp16x3", out_f32=True)
+    assert rel_l2(c, want) <= 5e-6, rel_l2(c, want)
+    assert c_hi.dtype == torch.float16 and rel_l2(ops.join(c_hi, c_lo), c) <= 2e-5
+    if lib.didi_gemm_small_workspace_bytes(M, N, K, ops.PRECISIONS["fp16x3"]):
+        _, _, cs = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), precision="fp16x3", out_f32=True, out_planes=False, small=())
+        assert rel_l2(cs, want) <= 5e-6
+    ids = ops.round_argmax(a_hi, a_lo, w_hi, w_lo, "fp16x3").cpu()
+    logits = a.double() @ w.double().t()
+    top2 = logits.topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5 * top2[:, 0].abs().clamp_min(1e-3)
+    assert torch.equal(ids[clear], logits.argmax(-1)[clear])
+    assert lib.didi_gemm_ln_supported(4096, 768, 768, ops.PRECISIONS["fp16x3"]) == 0
 
 
 def test_gemm_ln_rejects_unsupported(ops):
@@ -369,10 +400,8 @@ def test_round_argmax(ops, M, V, K, precision):
     x_hi, x_lo = ops.split(x.cuda(), dtype=PD[precision])
     w_hi, w_lo = ops.split(w.cuda(), dtype=PD[precision])
     ids = ops.round_argmax(x_hi, x_lo, w_hi, w_lo, precision).cpu()
-    if precision != "bf16x3":
-        logits = x_hi.cpu().double() @ w_hi.cpu().double().t()
-    else:
-        logits = x.double() @ w.double().t()
+    xr, wr = ref_operands(precision, x, w, x_hi, w_hi, w_lo)
+    logits = xr.double() @ wr.double().t()
     want = logits.argmax(-1)
     top2 = logits.topk(2, dim=-1).values
     gap = top2[:, 0] - top2[:, 1]
@@ -406,10 +435,8 @@ def test_round_ce(ops, M, V, K, precision):
     x_hi, x_lo = ops.split(x.cuda(), dtype=PD[precision])
     w_hi, w_lo = ops.split(w.cuda(), dtype=PD[precision])
     ids, nll = ops.round_ce(x_hi, x_lo, w_hi, w_lo, tg.cuda(), precision)
-    if precision != "bf16x3":
-        logits = x_hi.cpu().double() @ w_hi.cpu().double().t()
-    else:
-        logits = x.double() @ w.double().t()
+    xr, wr = ref_operands(precision, x, w, x_hi, w_hi, w_lo)
+    logits = xr.double() @ wr.double().t()
     want = torch.nn.functional.cross_entropy(logits, tg, reduction="none")
     tol = 2e-4 if precision == "bf16x3" else 2e-5  # bf16x3 drops the lo*lo product: logits to ~1e-5 of |x||w|
     assert (nll.cpu().double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item()), (nll.cpu().double() - want).abs().max()

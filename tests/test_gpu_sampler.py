@@ -3,8 +3,12 @@
 Bars (BASELINE.json north_star): with identical weights and identical injected noise,
   * bf16x3 ("fp32-class") : every denoiser input x_t rel-L2 <= 1e-4, logits rel-L2 <= 1e-4,
                             token ids identical on >= 99.9 % of positions;
-  * fp16                  : one product on fp16 planes: x_t rel-L2 <= 1e-3 (BASELINE.md bar "1e-3 in bf16";
-                            measured ~1.2e-4), logits <= 2e-3, token ids >= 99.9 % -- the same id bar as bf16x3;
+  * fp16x2 (bench default): fp16 planes, two products A_hi*(W_hi + W_lo): x_t rel-L2 <= 1e-3 (BASELINE.md bar "1e-3 in bf16"),
+                            logits <= 2e-3, token ids >= 99.9 % -- the same id bar as bf16x3, held at the benchmarked model
+                            size too (tests/test_gpu_fullsize.py);
+  * fp16                  : one product on fp16 planes: the same bars on these SMALL models (measured ~1.2e-4); at the
+                            benchmarked size it misses them (weight rounding adds up coherently over the loop), which is
+                            why it is no longer the default (DESIGN.md section 2);
   * bf16                  : x_t rel-L2 <= 1e-2 (north_star quotes 1e-3 "e.g."; measured values are
                             printed), ids reported, >= 97 % required on random-init weights whose
                             top-2 logit gaps are O(1e-1) (DESIGN.md "Precision").
@@ -39,7 +43,7 @@ TINY_CASES = ["tiny_ddpm_f1", "tiny_ddpm_f3_len8", "tiny_euler_f2", "tiny_euler_
 
 
 @pytest.mark.parametrize("name", TINY_CASES + ["tiny_bertenc_ddpm_f2", "tiny_t5enc_ddpm_f2", "tiny_t5gated_euler_f3"])
-@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x2", "fp16", "bf16"])
 def test_golden_cases(name, precision):
     from didi_amd.sampling import sample
 
@@ -63,7 +67,7 @@ def test_golden_cases(name, precision):
     if precision == "bf16x3":
         assert worst <= 1e-4 and lerr <= 1e-4
         assert match >= 0.999
-    elif precision == "fp16":
+    elif precision in ("fp16", "fp16x2"):
         assert worst <= 1e-3 and lerr <= 2e-3
         # >= 99.9 % of positions; the T5 cases have 48 positions, where ONE near-tie is 2 %: there an id may differ only
         # where the reference's own top-2 logits are closer than twice our largest logit deviation
@@ -79,7 +83,7 @@ def test_golden_cases(name, precision):
     assert torch.equal(ids.cpu()[clear], logits.argmax(-1).cpu()[clear])
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x2", "fp16", "bf16"])
 def test_config1_against_reference_fixture(precision):
     """BASELINE config 1 (V=8008, T=50, B=8, C=24): expected outputs come from the reference run."""
     from didi_amd.sampling import sample
@@ -96,7 +100,7 @@ def test_config1_against_reference_fixture(precision):
     worst = max(rel_l2(trace[i], t[f"xt.{i}"]) for i in meta["kept_calls"])
     match = (ids.cpu() == t["out.ids"]).float().mean().item()
     print(f"\n[config1 {precision}] max x_t rel-L2 {worst:.3e}  id match {match:.4f}")
-    assert worst <= {"bf16x3": 1e-4, "fp16": 1e-3, "bf16": 1e-2}[precision]
+    assert worst <= {"bf16x3": 1e-4, "fp16x2": 1e-3, "fp16": 1e-3, "bf16": 1e-2}[precision]
     assert match >= (0.97 if precision == "bf16" else 0.999)
     assert lengths.cpu().tolist() == [ids.shape[1]] * ids.shape[0]  # no tokenizer -> no eos -> full rows
 

@@ -1,8 +1,10 @@
 #!/bin/bash
 # Same-box A/B of two library builds: alternates bench runs (T=200) between DIDI_HIP_LIB=$1 and the in-tree library.
+# usage: tools/ab_bench.sh <other.so> [precision]
+P=${2:-fp16x2}
 for i in 1 2 3; do
   for lib in "$1" ""; do
-    DIDI_HIP_LIB=$lib python -u bench.py --diffusion-steps 200 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/ab_tmp.log 2>&1 || { echo failed; tail -3 gpurun_out/ab_tmp.log; exit 1; }
-    echo "${lib:-in-tree} $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/ab_tmp.log)"
+    DIDI_HIP_LIB=$lib timeout -k 10 300 python -u bench.py --diffusion-steps 200 --steps 2 --warmup 1 --no-cpu-baseline --precision $P > gpurun_out/ab_tmp.log 2>&1 || { echo failed; tail -3 gpurun_out/ab_tmp.log; exit 1; }
+    echo "${lib:-in-tree} $P $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/ab_tmp.log)"
   done
 done

@@ -110,6 +110,7 @@ class SampleArgs(C.Structure):
         ("ids64", C.c_void_p),
         ("prof_call", C.c_int), ("prof_events_host", C.POINTER(C.c_void_p)), ("prof_capacity", C.c_int),
         ("prof_used_host", C.POINTER(C.c_int)), ("clamp_emb", C.c_void_p), ("fault", C.c_void_p),
+        ("tail_calls", C.c_int), ("tail_precision", C.c_int),
     ]
 
 
@@ -129,7 +130,7 @@ SYMBOLS = [
                                     C.c_void_p]),
     ("didi_layernorm", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    ("didi_gemm_bf16", C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    ("didi_gemm", C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     ("didi_gemm_ln_supported", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("didi_gemm_ln_stats_bytes", C.c_size_t, [C.c_int]),
     ("didi_gemm_ln", C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,

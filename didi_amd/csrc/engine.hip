@@ -88,7 +88,7 @@ int gemm(const didi_linear& w, int precision, int M, const u16* a_hi, const u16*
     g.C_f32 = c_f32; g.C_hi = c_hi; g.C_lo = c_lo; g.ldc = ldc;
     if (prof) prof->mark(stream);
     const bool small = small_ws && small_enabled() && ldc == w.N && didi_gemm_small_workspace_bytes(M, w.N, w.K, precision);
-    const int rc = small ? didi_gemm_small(&g, nullptr, nullptr, 0.f, small_ws, stream) : didi_gemm_bf16(&g, stream);
+    const int rc = small ? didi_gemm_small(&g, nullptr, nullptr, 0.f, small_ws, stream) : didi_gemm(&g, stream);
     if (prof) prof->mark(stream);
     return rc;
 }
@@ -195,7 +195,8 @@ extern "C" int didi_decoder_prepare_context(const didi_decoder* dec, const float
 extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_args* a, void* stream) {
     DIDI_CHECK_ARG(dec && a && dec->layers_host && a->workspace && a->x0_f32 && a->kv_hi && a->ctx_mask);
     const int prec = a->precision;
-    DIDI_CHECK_ARG(prec == DIDI_PREC_BF16 || prec == DIDI_PREC_FP16 || prec == DIDI_PREC_FP16X2 || (prec == DIDI_PREC_BF16X3 && a->kv_lo));
+    DIDI_CHECK_ARG(prec == DIDI_PREC_BF16 || prec == DIDI_PREC_FP16 || prec == DIDI_PREC_FP16X2 || prec == DIDI_PREC_FP16X3 ||
+                   (prec == DIDI_PREC_BF16X3 && a->kv_lo));
     DIDI_CHECK_ARG(!(a->x0_lo && !a->x0_hi));
     if (!shapes_ok(dec, a->B, a->S, a->C)) return DIDI_ERR_UNSUPPORTED;
     if (a->S > 0 && dec->pos_emb == nullptr) return DIDI_ERR_BAD_ARG;
@@ -203,9 +204,14 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
     if (a->workspace_bytes < w.total) return DIDI_ERR_WORKSPACE;
     const int M = a->B * a->S, H = dec->H, I = dec->I, D = H / dec->heads;
     const bool x3 = prec == DIDI_PREC_BF16X3;
-    const bool f16 = prec == DIDI_PREC_FP16 || prec == DIDI_PREC_FP16X2;
+    const bool f16 = prec == DIDI_PREC_FP16 || prec == DIDI_PREC_FP16X2 || prec == DIDI_PREC_FP16X3;
     const int fmt = f16 ? DIDI_FMT_FP16 : DIDI_FMT_BF16;
-    const int attn_prec = prec == DIDI_PREC_FP16X2 ? DIDI_PREC_FP16 : prec;  // fp16x2 adds the weights' remainder; attention has no weights
+    // fp16x2 / fp16x3 add the remainders of the WEIGHTS (and, x3, of the GEMM inputs that carry one: the residual stream h and
+    // the GELU output); attention has no weights and its operands are single fp16 planes in every fp16 mode, so the projections
+    // that read the attention output run as fp16x2 inside an fp16x3 call
+    const int attn_prec = f16 ? DIDI_PREC_FP16 : prec;
+    const int proj_prec = prec == DIDI_PREC_FP16X3 ? DIDI_PREC_FP16X2 : prec;
+    const bool ffn_lo = x3 || prec == DIDI_PREC_FP16X3;
     const size_t Mc = (size_t)a->B * a->C;
     Prof prof{a->prof_events_host, a->prof_capacity, 0};
 
@@ -234,7 +240,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.V_hi = w.qkv_hi + 2 * H; at.V_lo = x3 ? w.qkv_lo + 2 * H : nullptr; at.ldv = 3 * H;
         at.O_hi = w.att_hi; at.O_lo = x3 ? w.att_lo : nullptr; at.ldo = H;
         TRY(didi_attention(&at, stream));
-        TRY(gemm_ln(ly.attn_out, prec, fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln1_g, ly.ln1_b,
+        TRY(gemm_ln(ly.attn_out, proj_prec, fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln1_g, ly.ln1_b,
                     dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault));
         // --- cross-attention block (K/V hoisted: didi_decoder_prepare_context)
         u16* q_hi = w.qkv_hi;
@@ -246,11 +252,11 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.K_hi = a->kv_hi + kvoff; at.K_lo = x3 ? a->kv_lo + kvoff : nullptr; at.ldk = 2 * H;
         at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;
         TRY(didi_attention(&at, stream));
-        TRY(gemm_ln(ly.cross_out, prec, fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln2_g, ly.ln2_b,
+        TRY(gemm_ln(ly.cross_out, proj_prec, fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln2_g, ly.ln2_b,
                     dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault));
         // --- feed-forward block
         TRY(gemm(ly.ffn_up, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_GELU, nullptr, nullptr, 0, nullptr, w.ffn_hi,
-                 x3 ? w.ffn_lo : nullptr, I, stream, &prof, w.small_ws, a->fault));
+                 ffn_lo ? w.ffn_lo : nullptr, I, stream, &prof, w.small_ws, a->fault));
         u16* o_hi = last && a->x0_hi ? a->x0_hi : w.h_hi;
         u16* o_lo = last && a->x0_hi ? a->x0_lo : w.h_lo;
         TRY(gemm_ln(ly.ffn_down, prec, fmt, M, w.ffn_hi, w.ffn_lo, I, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln3_g, ly.ln3_b,
@@ -268,6 +274,10 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
     if (s->ids64 && s->precision == DIDI_PREC_BF16X3) DIDI_CHECK_ARG(s->cls_lo && s->x0_lo);
     if (s->ids64 && s->precision == DIDI_PREC_FP16X2) DIDI_CHECK_ARG(s->cls_lo);
     if (s->clamp_emb) DIDI_CHECK_ARG(s->ids64 && s->x0_hi && s->x0_lo);
+    if (s->tail_calls > 0) {  // both precisions must work on the same plane format (the workspace planes and the K/V cache are shared)
+        auto is_f16 = [](int p) { return p == DIDI_PREC_FP16 || p == DIDI_PREC_FP16X2 || p == DIDI_PREC_FP16X3; };
+        DIDI_CHECK_ARG(is_f16(s->precision) && is_f16(s->tail_precision));
+    }
     if (!shapes_ok(dec, s->B, s->S, s->C)) return DIDI_ERR_UNSUPPORTED;
     const size_t MH = (size_t)s->B * s->S * dec->H;
     const uint64_t ctr_per_draw = MH / 4;
@@ -279,6 +289,8 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
     f.x0_f32 = s->x0_f32;
     f.fault = s->fault;
     auto draw = [&](int i) -> const float* { return s->noise ? s->noise + (size_t)i * MH : nullptr; };
+    // precision schedule: the last tail_calls denoiser calls run in tail_precision (same plane format as `precision`)
+    auto prec_of = [&](int k) { return s->tail_calls > 0 && k >= s->n_calls - s->tail_calls ? s->tail_precision : s->precision; };
     // per-step clamp extension: x0 <- emb[argmax(classifier(x0))]; the forward leaves x0 planes for the rounding GEMM
     const bool clamp = s->clamp_emb != nullptr;
     auto clamp_x0 = [&]() -> int {
@@ -310,6 +322,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
             st.t = s->time_row_host[k];
             st.xin_out = s->xt_trace ? s->xt_trace + (size_t)k * MH : nullptr;
             set_prof(k);
+            f.precision = prec_of(k);
             const bool last = k == s->n_calls - 1;
             f.x0_hi = last || clamp ? s->x0_hi : nullptr;
             f.x0_lo = last || clamp ? s->x0_lo : nullptr;
@@ -342,6 +355,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
             st.xin_out = s->xt_trace ? s->xt_trace + (size_t)k * MH : nullptr;
             f.x0_hi = clamp ? s->x0_hi : nullptr;
             f.x0_lo = clamp ? s->x0_lo : nullptr;
+            f.precision = prec_of(k);
             set_prof(k);
             TRY(didi_decoder_forward(dec, &f, stream));
             if (clamp) TRY(clamp_x0());
@@ -355,9 +369,9 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
         if (s->x0_hi) TRY(split_x0());
     }
     if (s->ids64) {
-        // the FINAL rounding of the fp16x2 mode multiplies all three products (once per batch: free): the ids then carry the
+        // the FINAL rounding of the fp16x2 mode (and of any precision schedule) multiplies all three products (once per batch: free): the ids then carry the
         // loop's error only, not the operand rounding of the classifier GEMM on top of it
-        const int round_prec = s->precision == DIDI_PREC_FP16X2 && s->x0_lo && s->cls_lo ? DIDI_PREC_FP16X3 : s->precision;
+        const int round_prec = (s->precision == DIDI_PREC_FP16X2 || s->tail_calls > 0) && s->x0_lo && s->cls_lo ? DIDI_PREC_FP16X3 : s->precision;
         TRY(didi_round_argmax(s->x0_hi, s->x0_lo, dec->H, s->cls_hi, s->cls_lo, dec->H, s->B * s->S, s->V, dec->H,
                               round_prec, s->argmax_partial, s->ids64, nullptr, stream));
     }

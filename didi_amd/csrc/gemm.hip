@@ -1113,7 +1113,7 @@ static const DeviceInfo* device_info() {
         ok = ok && opt_in_pp<3, false, true, false>() && opt_in_pp<1, false, true, false>() && opt_in_pp<1, true, true, false>();
         ok = ok && opt_in_pp<3, false, false, true>() && opt_in_pp<1, false, false, true>() && opt_in_pp<1, true, false, true>();
         ok = ok && opt_in_pp<2, true, false, false>() && opt_in_pp<2, true, true, false>() && opt_in_pp<2, true, false, true>();
-        ok = ok && opt_in_pp<3, true, false, false>() && opt_in_pp<3, true, false, true>();
+        ok = ok && opt_in_pp<3, true, false, false>() && opt_in_pp<3, true, false, true>() && opt_in_pp<3, true, true, false>();
         int c = 0;
         ok = ok && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0;
         d.ncu = c;
@@ -1132,7 +1132,7 @@ static void launch_big(GemmParams& p, hipStream_t st) {
 static inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 static inline bool al8(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; }
 
-extern "C" int didi_gemm_bf16(const didi_gemm_args* a, void* stream) {
+extern "C" int didi_gemm(const didi_gemm_args* a, void* stream) {
     DIDI_CHECK_ARG(a && a->A_hi && a->W_hi && a->M >= 0 && a->N > 0 && a->K > 0);
     DIDI_CHECK_ARG(a->C_f32 || a->C_hi);
     DIDI_CHECK_ARG(!(a->C_lo && !a->C_hi));
@@ -1380,7 +1380,8 @@ extern "C" int didi_gemm_small(const didi_gemm_args* a, const float* gamma, cons
 
 // ------------------------------------------------------------------ output projection + residual + LayerNorm
 extern "C" int didi_gemm_ln_supported(int M, int N, int K, int precision) {
-    const bool prec_ok = precision == DIDI_PREC_BF16 || precision == DIDI_PREC_FP16 || precision == DIDI_PREC_BF16X3 || precision == DIDI_PREC_FP16X2;
+    const bool prec_ok = precision == DIDI_PREC_BF16 || precision == DIDI_PREC_FP16 || precision == DIDI_PREC_BF16X3 ||
+                         precision == DIDI_PREC_FP16X2 || precision == DIDI_PREC_FP16X3;
     return prec_ok && M >= 2048 && N == 4 * BBN && K % 64 == 0 && K >= 128;
 }
 
@@ -1424,7 +1425,8 @@ extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const f
         p.C_hi = y_hi + r0 * a->N; p.C_lo = y_lo + r0 * a->N; p.C_f32 = y_f32 ? y_f32 + r0 * a->N : nullptr;
         p.ln_stats = reinterpret_cast<unsigned long long*>(stats) + (size_t)b0 * 4 * 512;
         const int grid = nb * 4;
-        if (p.npass == 3) gemm_pp_kernel<3, false, true><<<grid, 512, lds, st>>>(p);
+        if (p.npass == 3 && p.f16) gemm_pp_kernel<3, true, true><<<grid, 512, lds, st>>>(p);
+        else if (p.npass == 3) gemm_pp_kernel<3, false, true><<<grid, 512, lds, st>>>(p);
         else if (p.npass == 2) gemm_pp_kernel<2, true, true><<<grid, 512, lds, st>>>(p);
         else if (p.f16) gemm_pp_kernel<1, true, true><<<grid, 512, lds, st>>>(p);
         else gemm_pp_kernel<1, false, true><<<grid, 512, lds, st>>>(p);

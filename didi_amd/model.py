@@ -64,10 +64,16 @@ class _Classifier:
 
 
 class DiDiSampler:
-    def __init__(self, state_dict, cfg: DiDiConfig, device="cuda", precision="bf16x3"):
+    def __init__(self, state_dict, cfg: DiDiConfig, device="cuda", precision="bf16x3", tail_calls=0, tail_precision="fp16x3"):
+        """``precision``: bf16 | fp16 (one MFMA product), fp16x2 (weights with their remainder), bf16x3 (fp32-class).
+        ``tail_calls`` > 0: precision schedule for ``sample`` -- the LAST tail_calls denoiser calls of a loop run in
+        ``tail_precision`` (fp16 | fp16x2 | fp16x3; needs an fp16-plane ``precision``)."""
         if precision not in ("bf16", "fp16", "fp16x2", "bf16x3"):
             raise ValueError("precision must be one of bf16, fp16, fp16x2, bf16x3")
+        if tail_calls and (precision not in ("fp16", "fp16x2") or tail_precision not in ("fp16", "fp16x2", "fp16x3")):
+            raise ValueError("a precision schedule needs fp16-plane precisions: precision fp16|fp16x2, tail_precision fp16|fp16x2|fp16x3")
         self.cfg, self.device, self.precision = cfg, torch.device(device), precision
+        self.tail_calls, self.tail_precision = int(tail_calls), tail_precision
         sd = state_dict
         dev = self.device
         f = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
@@ -293,7 +299,11 @@ class DiDiSampler:
     def round_precision(self):
         """Precision of the classifier GEMM after the loop (rounding argmax, logits, cross-entropy): the fp16x2 mode spends
         all three products there (once per batch), as the engine's final rounding does."""
-        return "fp16x3" if self.precision == "fp16x2" else self.precision
+        return "fp16x3" if self.precision == "fp16x2" or self.tail_calls > 0 else self.precision
+
+    def prec_of_call(self, k, n_calls):
+        """C-ABI precision of denoiser call k of n_calls under the precision schedule."""
+        return ops.PRECISIONS[self.tail_precision if self.tail_calls > 0 and k >= n_calls - self.tail_calls else self.precision]
 
     def round_operands(self, x0_hi, x0_lo):
         """(x_hi, x_lo or None, precision) for ops.round_argmax / ops.round_ce on x0 planes."""

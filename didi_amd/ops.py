@@ -113,7 +113,7 @@ def gemm(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, precision="bf16x3", residu
         gamma, beta, eps = small if small else (None, None, 0.0)
         _lib.check(lib.didi_gemm_small(C.byref(g), _lib.ptr(gamma), _lib.ptr(beta), eps, ws.data_ptr(), _lib.current_stream()), "gemm_small")
     else:
-        _lib.check(lib.didi_gemm_bf16(C.byref(g), _lib.current_stream()), "gemm")
+        _lib.check(lib.didi_gemm(C.byref(g), _lib.current_stream()), "gemm")
     return c_hi, c_lo, c_f32
 
 

@@ -133,6 +133,7 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
         if clamp:
             a.clamp_emb = model.emb.weight.data_ptr()
         a.fault = b["fault"].data_ptr()
+        a.tail_calls, a.tail_precision = model.tail_calls, ops.PRECISIONS[model.tail_precision]
         if _prof is not None:  # bench.py: HIP events around the GEMM launches of one denoiser call
             a.prof_call, a.prof_events_host, a.prof_capacity = _prof.call, _prof.events, _prof.capacity
             a.prof_used_host = C.pointer(_prof.used)
@@ -170,9 +171,9 @@ def _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp=False):
         x0.copy_(ops.embed_gather(ids.view(B, S), model.emb.weight))
     noise = torch.randn((B, S, H), dtype=torch.float32, device=dev)  # sampling.py:13
 
-    def forward(step_kw, t):
+    def forward(step_kw, t, k):
         fa = _lib.ForwardArgs()
-        fa.B, fa.S, fa.C, fa.precision = B, S, Cn, model.prec
+        fa.B, fa.S, fa.C, fa.precision = B, S, Cn, model.prec_of_call(k, plan.n_calls)
         st = fa.step
         for k, v in step_kw.items():
             setattr(st, k, v)
@@ -198,7 +199,7 @@ def _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp=False):
             else:
                 noise.normal_(0, 1)  # sampling.py:54
                 kw = dict(mode=_lib.STEP_DDPM, X0=x0.data_ptr(), E=noise.data_ptr(), cx0=plan.a[k - 1], ce=plan.b[k - 1], cin=1.0)
-            forward(kw, plan.time_row[k])
+            forward(kw, plan.time_row[k], k)
     else:
         xs = b["x_state"]
         ops.step_embed_ln(_lib.STEP_INIT, B * S, S, H, E=noise, ce=plan.init_scale, x_out=xs)
@@ -207,7 +208,7 @@ def _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp=False):
             kw = dict(mode=_lib.STEP_EULER, X=xs.data_ptr(), X0=(xs if k == 0 else x0).data_ptr(),
                       ratio=0.0 if k == 0 else plan.ratio[k - 1], E=noise.data_ptr(), ce=plan.churn[k], cin=plan.c_in[k],
                       x_out=xs.data_ptr())
-            forward(kw, plan.time_row[k])
+            forward(kw, plan.time_row[k], k)
         ops.step_embed_ln(_lib.STEP_EULER, B * S, S, H, X=xs, X0=x0, ratio=plan.ratio[-1], ce=0.0, x_out=x0)
 
 

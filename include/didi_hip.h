@@ -87,9 +87,11 @@ enum { DIDI_PREC_BF16 = 1, DIDI_PREC_FP16 = 2, DIDI_PREC_BF16X3 = 3,
         * loop (the same perturbation of the model at every call); the activations' rounding does not.
         * Activation planes, attention and epilogues as DIDI_PREC_FP16; W_lo required, A_lo never read. */
        DIDI_PREC_FP16X2 = 4,
-       /* FP16X3: fp16 planes, all three products (A_hi*W_hi + A_hi*W_lo + A_lo*W_hi, ~22 bits): accepted by didi_gemm_bf16,
-        * didi_gemm_small, didi_round_argmax and didi_round_ce.  The engine uses it for the FINAL rounding of an FP16X2 loop
-        * (once per batch) and the Python side for materialised logits; the decoder loop itself does not take it. */
+       /* FP16X3: fp16 planes, all three products (A_hi*W_hi + A_hi*W_lo + A_lo*W_hi, ~22 bits): accepted by didi_gemm,
+        * didi_gemm_small, didi_gemm_ln, didi_round_argmax and didi_round_ce.  The engine uses it for the FINAL rounding of an
+        * fp16-plane loop (once per batch), the Python side for materialised logits, and didi_decoder_forward takes it as the
+        * tail precision of a sampling loop: the GEMMs whose input carries a remainder plane (residual stream, GELU output)
+        * multiply all three products, the two projections that read the attention output run as FP16X2, attention as FP16. */
        DIDI_PREC_FP16X3 = 5 };
 enum { DIDI_FMT_BF16 = 0, DIDI_FMT_FP16 = 1 }; /* element format of split planes */
 
@@ -172,7 +174,7 @@ int didi_layernorm(const float* x, const float* gamma, const float* beta, float 
 /* ---------------------------------------------------------------- GEMM (MFMA bf16) */
 
 /* C[M,N] = epilogue( sum_p A_p[M,K] * W_p[N,K]^T ), fp32 accumulation on
- * v_mfma_f32_16x16x32_bf16 / _f16 (the name keeps "bf16" from ABI v1; all three precisions go here).  W is an nn.Linear weight as stored ([out, in] = [N, K], K
+ * v_mfma_f32_16x16x32_bf16 / _f16 (every precision goes here; named didi_gemm_bf16 up to ABI 3).  W is an nn.Linear weight as stored ([out, in] = [N, K], K
  * contiguous), pre-split into planes.  Replaces every nn.Linear on the path:
  * Bert query/key/value/dense (HF:models/bert/modeling_bert.py:175-177,244,253-254,290,335,348),
  * the adapter (src/diffusion/model.py:123), `classifier` (src/sampling.py:64,82).
@@ -204,7 +206,7 @@ typedef struct didi_gemm_args {
     int ldc;
     uint32_t* fault;       /* device fault word (DIDI_FAULT_*) or NULL */
 } didi_gemm_args;
-int didi_gemm_bf16(const didi_gemm_args* a, void* stream);
+int didi_gemm(const didi_gemm_args* a, void* stream);
 
 /* y = LayerNorm(A W^T + bias + residual): BertSelfOutput / BertOutput in one launch -- `dense` +
  * dropout(eval) + `LayerNorm(hidden_states + input_tensor)` (HF:models/bert/modeling_bert.py:284-295,342-353).
@@ -216,7 +218,7 @@ int didi_gemm_bf16(const didi_gemm_args* a, void* stream);
  * split planes y_hi / y_lo (format of the precision; may alias the residual planes) and, if not NULL, fp32
  * y_f32, all [M, N] dense.  Supported (didi_gemm_ln_supported != 0): N == 768 (BertConfig hidden size: the
  * decoder of every DiDi config), M >= 2048, K % 64 == 0, any precision; otherwise DIDI_ERR_UNSUPPORTED and the
- * caller runs didi_gemm_bf16 + didi_layernorm.  `stats`: didi_gemm_ln_stats_bytes(M) bytes, 16-byte aligned: the
+ * caller runs didi_gemm + didi_layernorm.  `stats`: didi_gemm_ln_stats_bytes(M) bytes, 16-byte aligned: the
  * statistics travel as 8-byte {tag = epoch, value} words.  On entry no word of it may carry `epoch` in its upper half:
  * zero the buffer once (hipMemsetAsync), then pass epoch = 1, 2, 3, ... to successive calls that share it;
  * epoch == 0 makes the call zero the buffer itself and use tag 1 (stand-alone use).
@@ -230,10 +232,10 @@ size_t didi_gemm_ln_stats_bytes(int M);
 int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, uint16_t* y_hi,
                  uint16_t* y_lo, float* y_f32, void* stats, uint32_t epoch, void* stream);
 
-/* Small batches (M < 2048 rows: interactive use, a handful of dialogs).  The same arithmetic as didi_gemm_bf16 (+ an
+/* Small batches (M < 2048 rows: interactive use, a handful of dialogs).  The same arithmetic as didi_gemm (+ an
  * optional LayerNorm over the N output columns: gamma/beta non-NULL, as didi_gemm_ln), organised for latency: K is split
  * over workgroups, the partial sums go through `workspace` (didi_gemm_small_workspace_bytes(M, N, K, precision) bytes,
- * 16-byte aligned; 0 = this form does not apply, use didi_gemm_bf16), and one row kernel applies bias, activation,
+ * 16-byte aligned; 0 = this form does not apply, use didi_gemm), and one row kernel applies bias, activation,
  * residual, LayerNorm and writes the outputs (ldc == N).  N <= 3072, N % 4 == 0, K % 128 == 0. */
 size_t didi_gemm_small_workspace_bytes(int M, int N, int K, int precision);
 int didi_gemm_small(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, void* workspace, void* stream);
@@ -398,7 +400,7 @@ int didi_decoder_forward(const didi_decoder* dec, const didi_forward_args* a, vo
 /* The whole reverse-diffusion loop of sample_ddpm / sample_euler (src/sampling.py:38-101) for one
  * batch, enqueued back to back with no host round trip: n_calls denoiser calls driven by the
  * host-side plan rows (didi_amd/schedule.py), the rounding argmax at the end when ids64 != NULL,
- * logits via didi_gemm_bf16 by the caller otherwise.
+ * logits via didi_gemm by the caller otherwise.
  *   euler == 0: ddpm.  plan rows: time_row[k], c0[k] = a_k, c1[k] = b_k        (k = 0..n_calls-1)
  *   euler != 0:        plan rows: time_row[k], c0[k] = churn_k, c1[k] = c_in_k, c2[k] = ratio_k
  *   init_scale: x_T = init_scale * eps_0 (ddpm: already includes scale_input(., sigma_T))
@@ -442,6 +444,12 @@ typedef struct didi_sample_args {
      * rounding fields above (cls_*, V, argmax_partial, ids64 as scratch, x0_hi/x0_lo). */
     const float* clamp_emb;
     uint32_t* fault; /* device fault word (DIDI_FAULT_*) or NULL; watched over the whole loop */
+    /* precision schedule (0 = none): the LAST tail_calls denoiser calls run in tail_precision instead of `precision`; both must be
+     * fp16-plane precisions (FP16, FP16X2, FP16X3).  The error of the early, noise-dominated calls is forgotten within a few
+     * dozen steps; what the final ids carry is the rounding of the last calls, so the extra products are spent only there
+     * (DESIGN.md section 2). */
+    int tail_calls;
+    int tail_precision;
 } didi_sample_args;
 int didi_sample(const didi_decoder* dec, const didi_sample_args* a, void* stream);
 

@@ -27,14 +27,14 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-PD = {"bf16": torch.bfloat16, "fp16": torch.float16, "bf16x3": torch.bfloat16, "fp16x2": torch.float16}  # plane dtype per precision
+PD = {"bf16": torch.bfloat16, "fp16": torch.float16, "bf16x3": torch.bfloat16, "fp16x2": torch.float16, "fp16x3": torch.float16}  # plane dtype per precision
 ALL_PREC = ["bf16", "fp16", "bf16x3", "fp16x2"]
 
 
 def ref_operands(precision, a, w, a_hi, w_hi, w_lo):
     """The operands a precision multiplies, as fp32 CPU tensors: one product = the hi planes; fp16x2 = A_hi x (W_hi + W_lo);
     bf16x3 = the un-rounded values (its split carries ~16 bits, the lo*lo term is dropped: tolerance 3e-5)."""
-    if precision == "bf16x3":
+    if precision in ("bf16x3", "fp16x3"):
         return a, w
     if precision == "fp16x2":
         return a_hi.cpu().float(), (w_hi.float() + w_lo.float()).cpu()
@@ -237,7 +237,7 @@ def test_gemm_epilogues(ops, act, resid):
 @pytest.mark.parametrize("ln", [False, True])
 def test_gemm_small_batch_form(ops, M, N, K, precision, ln):
     """didi_gemm_small (split-K + row epilogue) == [LayerNorm](gelu(A W^T + bias) + residual) on the same rounded operands, and
-    agrees with the plain launch of didi_gemm_bf16 to summation-order rounding."""
+    agrees with the plain launch of didi_gemm to summation-order rounding."""
     from didi_amd._lib import lib
 
     a, w, bias, r = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=0.05), rnd(N, seed=43), rnd(M, N, seed=44)
@@ -296,7 +296,7 @@ def test_gemm_big_tile(ops, M, N, K, precision):
 
 
 @pytest.mark.parametrize("M,K", [(2048, 768), (2100, 128), (4160, 3072), (16684, 128)])
-@pytest.mark.parametrize("precision", ALL_PREC)
+@pytest.mark.parametrize("precision", ALL_PREC + ["fp16x3"])
 def test_gemm_ln_fused(ops, M, K, precision):
     """didi_gemm_ln == LayerNorm(A W^T + bias + residual) (fp64 reference on the same rounded operands), ragged last
     row band, more bands than one launch holds (16684 rows = 66 bands > 256 CUs / 4), in place over the residual."""
@@ -325,7 +325,7 @@ def test_gemm_ln_fused(ops, M, K, precision):
 def test_gemm_and_rounding_fp16x3(ops, M, N, K):
     """DIDI_PREC_FP16X3 (all three products on fp16 planes, ~22 bits; the final rounding / logits of the fp16x2 mode): 128x128 tile,
     256x192 tile and the split-K small-batch form against fp64 on the UN-rounded operands at 5e-6; rounding ids exact where the
-    top-2 gap is not a near-tie; LayerNorm-fused launches do not take this precision."""
+    top-2 gap is not a near-tie (the LayerNorm-fused launch in this precision: test_gemm_ln_fused)."""
     from didi_amd._lib import lib
 
     a, w, bias = rnd(M, K, seed=61), rnd(N, K, seed=62, scale=0.05), rnd(N, seed=63)
@@ -343,7 +343,7 @@ def test_gemm_and_rounding_fp16x3(ops, M, N, K):
     top2 = logits.topk(2, dim=-1).values
     clear = (top2[:, 0] - top2[:, 1]) > 1e-5 * top2[:, 0].abs().clamp_min(1e-3)
     assert torch.equal(ids[clear], logits.argmax(-1)[clear])
-    assert lib.didi_gemm_ln_supported(4096, 768, 768, ops.PRECISIONS["fp16x3"]) == 0
+    assert lib.didi_gemm_ln_supported(4096, 768, 768, ops.PRECISIONS["fp16x3"]) == 1
 
 
 def test_gemm_ln_rejects_unsupported(ops):

@@ -302,6 +302,53 @@ def test_torch_noise_loop_equals_native_loop():
     assert torch.equal(l_torch, l_native)
 
 
+@pytest.mark.parametrize("name", ["tiny_ddpm_f1", "tiny_euler_churn_f4"])
+def test_precision_schedule_tail(name):
+    """Precision schedule: the last `tail_calls` denoiser calls of a loop run in fp16x3 (all three products on fp16 planes).
+    (a) a tail that covers every call is an fp32-class sampler: x_t within 1e-4 of the reference fixture, ids identical;
+    (b) tail 0 is bit-identical to the plain precision; (c) a partial tail only changes calls from its first one on;
+    (d) the per-call Python loop honours the same schedule bit for bit."""
+    from didi_amd.model import DiDiSampler
+    from didi_amd.sampling import sample
+
+    t, meta = load_case(name)
+    run, n_calls = meta["run"], int(meta["n_calls"])
+    w = weights_of(load_case("tiny_weights")[0])
+    cfg = spec_to_config(meta["spec"])
+    noise = torch.stack(noise_list(t, int(meta["n_noise"])))
+    ctx = _ctx(t["in.input_ids"], t["in.attention_mask"])
+
+    def go(model, **kw):
+        tr = []
+        ids, _ = sample(ctx, model, run["mode"], run["step_freq"], max_len=run["max_len"], noise=noise, return_ids=True, trace=tr, **kw)
+        model.check_fault(name)
+        return ids.cpu(), tr
+
+    full = DiDiSampler(w, cfg, device="cuda", precision="fp16", tail_calls=n_calls, tail_precision="fp16x3")
+    ids, tr = go(full)
+    worst = max(rel_l2(x, t[f"xt.{i}"]) for i, x in enumerate(tr))
+    print(f"\n[{name} fp16 + fp16x3 tail over all {n_calls} calls] max x_t rel-L2 {worst:.3e}  id match {(ids == t['out.ids']).float().mean().item():.4f}")
+    assert worst <= 1e-4 and torch.equal(ids, t["out.ids"])
+    plain_ids, plain_tr = go(DiDiSampler(w, cfg, device="cuda", precision="fp16x2"))
+    zero_ids, zero_tr = go(DiDiSampler(w, cfg, device="cuda", precision="fp16x2", tail_calls=0))
+    assert torch.equal(plain_ids, zero_ids) and all(torch.equal(a, b) for a, b in zip(plain_tr, zero_tr))
+    k0 = n_calls - 2
+    part = DiDiSampler(w, cfg, device="cuda", precision="fp16x2", tail_calls=2, tail_precision="fp16x3")
+    _, part_tr = go(part)
+    assert all(torch.equal(a, b) for a, b in zip(plain_tr[: k0 + 1], part_tr[: k0 + 1])), "calls before the tail are untouched"
+    assert not torch.equal(plain_tr[-1], part_tr[-1]), "the tail's first call runs in another precision: the next input differs"
+    with pytest.raises(ValueError):
+        DiDiSampler(w, cfg, device="cuda", precision="bf16x3", tail_calls=2)
+    # the Python loop (torch-drawn noise) follows the same schedule as the native loop
+    shape = tuple(t["noise.0"].shape)
+    torch.cuda.manual_seed(3)
+    a = sample(ctx, part, run["mode"], run["step_freq"], max_len=run["max_len"], raw_output=True, noise="torch")
+    torch.cuda.manual_seed(3)
+    draws = [torch.randn(shape, device="cuda")] + [torch.empty(shape, device="cuda").normal_(0, 1) for _ in range(int(meta["n_noise"]) - 1)]
+    b = sample(ctx, part, run["mode"], run["step_freq"], max_len=run["max_len"], raw_output=True, noise=torch.stack(draws))
+    assert torch.equal(a, b)
+
+
 def test_full_size_decoder_properties():
     """cfg2-sized model (H=768, 12 layers, 12 heads, FFN 3072; enc 1280/32 heads/5120), S=C=64.
     (a) a B=2 slice agrees with the CPU oracle; (b) dialogs are independent: the same dialogs give

@@ -7,6 +7,7 @@ import time
 
 import torch
 
+from didi_amd import _lib
 from didi_amd.config import DiDiConfig
 from didi_amd.model import DiDiSampler
 from didi_amd.sampling import sample
@@ -14,7 +15,19 @@ from didi_amd.synthetic import RawContext, synthetic_batch, synthetic_state_dict
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 layout = sys.argv[2] if len(sys.argv) > 2 else "split"
-hip = C.CDLL("libamdhip64.so")
+
+
+def _loaded_hip_runtime():
+    """The HIP runtime torch (and libdidi_hip) already run on: a second copy loaded by name would not share their streams."""
+    for line in open("/proc/self/maps"):
+        path = line.split()[-1]
+        if "libamdhip64" in path:
+            return C.CDLL(path)
+    raise RuntimeError("no libamdhip64 mapped into this process")
+
+
+torch.cuda.init()
+hip = _loaded_hip_runtime()
 
 
 def masked_stream(words):
@@ -25,6 +38,8 @@ def masked_stream(words):
     return torch.cuda.ExternalStream(st.value)
 
 
+# two samplers share the GPU here: the fused projection + LayerNorm needs the device to itself (its band mates must be co-resident)
+_lib.set_option("GEMM_LN", 0)
 cfg = DiDiConfig(diffusion_steps=T)
 sd = synthetic_state_dict(cfg, seed=1234)
 ids, mask = synthetic_batch(256, 64, cfg.vocab, seed=3)

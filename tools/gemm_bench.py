@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of didi_gemm_bf16 on the decoder's shapes (M = B*S rows), both precisions.
+"""Micro-benchmark of didi_gemm on the decoder's shapes (M = B*S rows), both precisions.
 
     python tools/gemm_bench.py [--M 16384] [--iters 30]
 

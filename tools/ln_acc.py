@@ -1,4 +1,4 @@
-"""Accuracy of didi_gemm_ln vs didi_gemm_bf16 + didi_layernorm against an fp64 reference (same rounded operands)."""
+"""Accuracy of didi_gemm_ln vs didi_gemm + didi_layernorm against an fp64 reference (same rounded operands)."""
 import torch
 from didi_amd import ops
 

@@ -62,3 +62,16 @@ def get_euler_variables(x_t, noise, sigma_t, s_churn, s_tmin, s_tmax, num_sigmas
     if gamma > 0:
         x_t = x_t + (sigma_hat**2 - sigma_t**2) ** 0.5 * noise
     return x_t, sigma_hat
+
+
+def get_x0(emb, std, noise):
+    # reference: src/diffusion/utils.py:24-27 (its randn_like is the caller-supplied `noise` here)
+    return emb + std * noise
+
+
+def get_diffusion_variables(x_0, sigmas, noise, t, noise_factor=1):
+    """reference: src/diffusion/utils.py:34-40.  The reference draws ``t = randint(1, T + 1, [B, 1])`` itself; here the
+    caller passes it (tests inject the captured draw), so the function is deterministic."""
+    sigma_t = sigmas[t].view(-1, 1, 1)
+    x_t = scale_input(x_0 + sigma_t * noise * noise_factor**2, sigma_t)
+    return x_t, t

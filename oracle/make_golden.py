@@ -225,11 +225,115 @@ def t5_cases():
         save_case(name, spec, run, logits, draws, calls, ctx.detach(), ids, mask, weights=state_dict_of(m))
 
 
+def ref_training_step(model, ctx, tgt, anchor_loss, noise_factor, tap):
+    """DiDi.training_step (src/diffusion/model.py:200-243) around the HF modules, line for line, with the reference's own
+    ``get_x0`` / ``get_diffusion_variables`` / ``scale_input`` imported from /root/reference (they import only torch).
+    ``calculate_batch_ce`` (src/metrics.py:91-93) and ``flat_mean`` (model.py:62-63) are restated: their modules import
+    loguru / lightning, which are not installed.  Returns everything the fixture stores."""
+    import torch.nn.functional as F
+    from src.diffusion.utils import get_diffusion_variables, get_x0, scale_input
+
+    def calculate_batch_ce(logits, target, non_pad_mask):  # metrics.py:91-93
+        non_pad_mask = non_pad_mask.bool().view(-1)
+        return F.cross_entropy(logits.view(-1, logits.shape[-1])[non_pad_mask], target.view(-1)[non_pad_mask])
+
+    def flat_mean(tensor):  # model.py:62-63
+        return tensor.mean(dim=list(range(1, len(tensor.shape))))
+
+    emb = model.emb(tgt.input_ids)
+    x_0 = get_x0(emb, model.std_0)
+    noise = torch.randn_like(x_0)
+    x_t, t = get_diffusion_variables(model.diffusion_steps, x_0, model.sigmas, noise, noise_factor)
+    x_0_hat, _ = model(encoder_input_ids=ctx.input_ids, encoder_attention_mask=ctx.attention_mask, decoder_inputs_embeds=x_t, time_ids=t)
+    x_0_hat.retain_grad()
+    logits = model.classifier(x_0_hat) if anchor_loss else model.classifier(x_0)
+    ce = calculate_batch_ce(logits, tgt.input_ids, tgt.attention_mask)
+    non_pad_mask = tgt.attention_mask.unsqueeze(-1)
+    # t is [B, 1] and flat_mean gives [B]: torch.where broadcasts to [B, B] -- reproduced as written (model.py:222-227)
+    mse = torch.where(t == 1, flat_mean((x_0_hat - emb) ** 2 * non_pad_mask), flat_mean((x_0_hat - x_0) ** 2 * non_pad_mask)).mean()
+    noise2, sigma_T = torch.randn_like(x_0), model.sigmas[-1]  # model.py:229: drawn, never used
+    x_T = scale_input(x_0, sigma_T)
+    t_T_loss = (x_T**2 * non_pad_mask).mean()
+    loss = mse + ce
+    if not anchor_loss:
+        loss = loss + t_T_loss
+    with torch.no_grad():
+        ce_hat = calculate_batch_ce(model.classifier(x_0_hat), tgt.input_ids, tgt.attention_mask)
+    return dict(emb=emb, x_0=x_0, x_t=x_t, t=t, x_0_hat=x_0_hat, mse=mse, ce=ce, t_T=t_T_loss, loss=loss, ce_hat=ce_hat)
+
+
+def training_cases():
+    """(T) DiDi.training_step on the tiny model (same weights as tiny_weights.safetensors): the RNG draws in the reference's order
+    (get_x0's randn_like, the noise randn_like, randint for t -- captured as `t` --, the dead randn_like of model.py:229), x_t,
+    x_0_hat, the five logged scalars, and the gradients autograd gives: every trainable parameter's, plus the intermediates of
+    the LAST decoder layer's feed-forward block (BertIntermediate output, BertOutput.dense output + residual, their gradients),
+    which pin the GEMM and LayerNorm backward kernels one at a time.  The encoder is frozen (configs/train.yaml:19)."""
+    model = build_model(TINY, seed=11)
+    for p_ in model.encoder.parameters():
+        p_.requires_grad_(False)  # freeze_params(self.encoder), model.py:114-115
+    V = TINY["vocab"]
+    ids, mask = make_inputs(4, 12, V, seed=5)
+    tids, tmask = make_inputs(4, 10, V, seed=8, min_len=3)
+    last = model.decoder.encoder.layer[-1]
+    for name, anchor, nf in (("train_tiny_plain", False, 1.0), ("train_tiny_anchor_nf2", True, 2.0)):
+        for seed in range(300, 400):  # a seed whose randint gives some (not all) rows t == 1: both branches of the mse `where`
+            torch.manual_seed(seed)
+            _ = torch.randn(4, 10, TINY["dec_dim"]), torch.randn(4, 10, TINY["dec_dim"])
+            t_try = torch.randint(1, TINY["T"] + 1, size=(4, 1))
+            if 0 < int((t_try == 1).sum()) < 4:
+                break
+        model.zero_grad(set_to_none=True)
+        stash = {}
+        def keep(key, pick, grad=True):  # a forward hook that returns None (a returned value would replace the output)
+            def hook(m, i, o):
+                v = pick(i, o)
+                if grad:
+                    v.retain_grad()
+                stash[key] = v
+            return hook
+
+        hooks = [
+            last.intermediate.register_forward_hook(keep("ffn", lambda i, o: o)),
+            last.output.LayerNorm.register_forward_hook(keep("ln_in", lambda i, o: i[0])),
+            last.output.register_forward_hook(keep("resid", lambda i, o: i[1], grad=False)),
+        ]
+        torch.manual_seed(seed)
+        with NoiseTap() as tap:
+            r = ref_training_step(model, Ctx(ids, mask), Ctx(tids, tmask), anchor, nf, tap)
+        r["loss"].backward()
+        for h in hooks:
+            h.remove()
+        assert torch.equal(r["t"], t_try), "the seed search must replay the reference's draw order"
+        t = {"in.input_ids": ids, "in.attention_mask": mask, "in.target_ids": tids, "in.target_mask": tmask,
+             "t": r["t"].contiguous(), "out.emb": r["emb"].detach().contiguous(), "out.x_0": r["x_0"].detach().contiguous(),
+             "out.x_t": r["x_t"].detach().contiguous(), "out.x_0_hat": r["x_0_hat"].detach().contiguous(),
+             "out.scalars": torch.stack([r[k].detach() for k in ("mse", "ce", "t_T", "loss", "ce_hat")]),
+             "grad.x_0_hat": r["x_0_hat"].grad.contiguous(),
+             "last.ffn": stash["ffn"].detach().contiguous(), "last.ffn.grad": stash["ffn"].grad.contiguous(),
+             "last.resid": stash["resid"].detach().contiguous(),
+             "last.ln_in": stash["ln_in"].detach().contiguous(), "last.ln_in.grad": stash["ln_in"].grad.contiguous()}
+        for i, d in enumerate(tap.draws):
+            t[f"noise.{i}"] = d.contiguous()
+        n_grads = 0
+        for n, p_ in model.named_parameters():
+            if p_.grad is not None:
+                t["g." + n] = p_.grad.detach().clone().contiguous()
+                n_grads += 1
+        meta = {"spec": json.dumps(TINY), "run": json.dumps(dict(anchor_loss=anchor, noise_factor=nf, seed=seed)),
+                "n_noise": str(len(tap.draws)), "n_grads": str(n_grads)}
+        save_file(t, os.path.join(OUT, name + ".safetensors"), metadata=meta)
+        print(f"wrote {name}: seed {seed}, t = {r['t'].view(-1).tolist()}, scalars {[round(float(r[k]), 6) for k in ('mse', 'ce', 't_T', 'loss', 'ce_hat')]}, "
+              f"{n_grads} parameter gradients, {len(tap.draws)} draws")
+
+
 def main():
     sys.path.insert(0, REF)
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "t5":  # add the T5 cases without regenerating the others
         t5_cases()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "train":  # add the training-step cases without regenerating the others
+        training_cases()
         return
     from src.diffusion.utils import configure_schedule
 
@@ -306,6 +410,7 @@ def main():
                         "n_noise": str(len(draws)), "n_calls": str(len(calls)), "kept_calls": json.dumps(keep)})
     print("wrote config1_ddpm; weights sha256", sd_hash(w1)[:16])
     t5_cases()
+    training_cases()
 
 
 if __name__ == "__main__":

@@ -113,3 +113,28 @@ def test_sample_errors_match_reference():
         sample(ctx, model, "ddpm", 5)
     with pytest.raises(ValueError):  # src/diffusion/model.py:180-181
         model(decoder_inputs_embeds=t["xt.0"], time_ids=torch.ones(4, 1, dtype=torch.long))
+
+
+@pytest.mark.parametrize("name", ["train_tiny_plain", "train_tiny_anchor_nf2"])
+def test_training_step_oracle_matches_reference_fixture(name):
+    """oracle/training.py against DiDi.training_step run on the HF modules (oracle/make_golden.py train): x_t, x_0_hat, the five
+    logged scalars and EVERY trainable parameter's gradient (63 tensors), with the captured draws and t injected."""
+    from oracle.training import training_step_with_grads
+
+    t, meta = load_case(name)
+    run = meta["run"]
+    w = weights_of(load_case("tiny_weights")[0])
+    draws = noise_list(t, int(meta["n_noise"]))
+    out, grads = training_step_with_grads(w, spec_to_oracle_config(meta["spec"]), Context(t["in.input_ids"], t["in.attention_mask"]),
+                                          Context(t["in.target_ids"], t["in.target_mask"]), draws, t["t"],
+                                          anchor_loss=run["anchor_loss"], noise_factor=run["noise_factor"])
+    assert bool((t["t"] == 1).any()) and not bool((t["t"] == 1).all()), "the fixture exercises both branches of the mse `where`"
+    assert rel_l2(out["x_t"], t["out.x_t"]) <= 1e-6 and rel_l2(out["x_0_hat"].detach(), t["out.x_0_hat"]) <= 1e-5
+    got = torch.stack([out[k].detach() for k in ("mse", "ce", "t_T", "loss", "ce_hat")])
+    assert torch.allclose(got, t["out.scalars"], rtol=1e-5, atol=1e-9), (got, t["out.scalars"])
+    want = {k[2:]: v for k, v in t.items() if k.startswith("g.")}
+    assert len(want) == int(meta["n_grads"]) == 63
+    # HF keeps `classifier` / `emb` etc. under the same names; the decoder's unused word embeddings and pooler get no gradient
+    for k, g in want.items():
+        assert k in grads, k
+        assert rel_l2(grads[k], g) <= 2e-5 or (g.norm() < 1e-12 and grads[k].norm() < 1e-9), (k, rel_l2(grads[k], g))

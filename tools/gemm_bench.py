@@ -24,7 +24,10 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--H", type=int, default=768)
     ap.add_argument("--I", type=int, default=3072)
+    ap.add_argument("--precisions", default="fp16,fp16x2,bf16x3")
     args = ap.parse_args()
+    precs = args.precisions.split(",")
+    MULT = {"bf16x3": 3, "fp16x3": 3, "fp16x2": 2}
     M, H, I = args.M, args.H, args.I
     g = torch.Generator(device="cuda").manual_seed(0)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)  # noqa: E731
@@ -35,11 +38,11 @@ def main():
         ("ffn_up   gelu", I, H, dict(act="gelu")),
         ("ffn_down f32+res", H, I, dict(resid=True)),
     ]
-    total = {"fp16": 0.0, "bf16x3": 0.0}
+    total = {p: 0.0 for p in precs}
     for name, N, K, kw in shapes:
         a32, w32, r32 = rnd(M, K), rnd(N, K) * 0.02, rnd(M, N)
         bias = rnd(N)
-        for prec in ("fp16", "bf16x3"):
+        for prec in precs:
             pd = ops.plane_dtype(prec)
             a_hi, a_lo = ops.split(a32, dtype=pd)
             w_hi, w_lo = ops.split(w32, dtype=pd)
@@ -57,13 +60,13 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / args.iters
             fl = 2.0 * M * N * K
-            mult = 3 if prec == "bf16x3" else 1
+            mult = MULT.get(prec, 1)
             total[prec] += us * (2 if name.startswith('attn_out') else 1)
             print(f"{name:18s} N={N:5d} K={K:5d} {prec:7s} {us:8.1f} us  alg {fl / us / 1e6:7.1f} TF  exec {mult * fl / us / 1e6:7.1f} TF")
     # output projection + residual + LayerNorm: fused launch vs GEMM + LayerNorm
     if H == 768:
         gam, bet = torch.ones(H, device="cuda"), torch.zeros(H, device="cuda")
-        for prec in ("fp16", "bf16x3"):
+        for prec in precs:
             pd = ops.plane_dtype(prec)
             for K in (H, I):
                 a_hi, a_lo = ops.split(rnd(M, K), dtype=pd)

@@ -156,6 +156,17 @@ SYMBOLS = [
                                                C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("didi_decoder_forward", C.c_int, [C.POINTER(Decoder), C.POINTER(ForwardArgs), C.c_void_p]),
     ("didi_sample", C.c_int, [C.POINTER(Decoder), C.POINTER(SampleArgs), C.c_void_p]),
+    ("didi_train_noise", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("didi_train_loss_terms", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("didi_train_mse_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p]),
+    ("didi_layernorm_backward_bytes", C.c_size_t, [C.c_int, C.c_int]),
+    ("didi_layernorm_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("didi_colsum_bytes", C.c_size_t, [C.c_int, C.c_int]),
+    ("didi_colsum", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("didi_transpose_split", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     ("didi_event_create", C.c_int, [C.POINTER(C.c_void_p)]),
     ("didi_event_elapsed_ms", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     ("didi_event_destroy", C.c_int, [C.c_void_p]),

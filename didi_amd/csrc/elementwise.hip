@@ -7,42 +7,7 @@
 // each kernel; DESIGN.md section "Kernels" carries the roofline arithmetic.
 #include "common.hpp"
 
-// ------------------------------------------------------------------ Philox4x32-10 + Box-Muller
-__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t key, uint32_t out[4]) {
-    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
-    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        c1 = (uint32_t)p1;
-        c3 = (uint32_t)p0;
-        c0 = n0;
-        c2 = n2;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__device__ __forceinline__ void philox_normal4(uint64_t ctr, uint64_t seed, float z[4]) {
-    uint32_t r[4];
-    philox4x32_10(ctr, seed, r);
-    const float k = 2.3283064365386963e-10f;  // 2^-32
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const float u1 = ((float)r[2 * p] + 0.5f) * k;  // (0, 1]
-        const float u2 = ((float)r[2 * p + 1] + 0.5f) * k;
-        // hardware transcendentals: v_log_f32 (log2), v_sin/v_cos_f32 (argument in revolutions, so 2*pi*u2 is never formed).
-        // The library logf/sincosf cost this kernel a third of its run time (34 -> 2x us at cfg2) for digits the noise does not need;
-        // against the numpy oracle the normals differ by < 5e-5 absolute (tests/test_gpu_kernels.py).
-        const float rad = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
-        z[2 * p] = rad * __builtin_amdgcn_cosf(u2);
-        z[2 * p + 1] = rad * __builtin_amdgcn_sinf(u2);
-    }
-}
+#include "philox.hpp"
 
 __global__ void __launch_bounds__(256) philox_normal_kernel(float* out, size_t n4, uint64_t seed, uint64_t offset) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {

@@ -93,6 +93,8 @@ class DiDiSampler:
         else:
             self._sigmas_host, _ = configure_schedule(cfg.diffusion_steps, cfg.schedule)
         self.sigmas = self._sigmas_host.to(dev)
+        # std_0 = sqrt(beta_0) (configure_schedule's second value; model.py:125-127): read by the training step's get_x0
+        self.std_0 = float(sd["std_0"]) if "std_0" in sd else float(configure_schedule(cfg.diffusion_steps, cfg.schedule)[1])
         self._build_decoder(sd, f)
         self._build_encoder(sd, f)
         self._bufs = {}

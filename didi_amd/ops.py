@@ -236,3 +236,88 @@ def step_embed_ln(mode, M, S, H, *, X=None, X0=None, E=None, cx0=0.0, ce=0.0, ra
     a.h_hi, a.h_lo = _lib.ptr(h_hi), _lib.ptr(h_lo)
     a.plane_format = _fmt(h_hi.dtype) if h_hi is not None else _lib.FMT_BF16
     _lib.check(lib.didi_step_embed_ln(C.byref(a), _lib.current_stream()), "step_embed_ln")
+
+
+# ------------------------------------------------------------------ training-step kernels (didi_amd/csrc/train.hip)
+def train_noise(emb, s_b, c_b, std0, n0=None, n1=None, seed=0, offset=0):
+    """emb fp32 [B,S,H]; s_b, c_b fp32 [B] -> (x_0, x_t) fp32 [B,S,H].  n0 / n1: injected draws or None (in-kernel Philox)."""
+    emb = _f32c(emb)
+    B, S, H = emb.shape
+    x0, xt = torch.empty_like(emb), torch.empty_like(emb)
+    _lib.check(lib.didi_train_noise(emb.data_ptr(), _lib.ptr(n0), _lib.ptr(n1), float(std0), _f32c(s_b).data_ptr(), _f32c(c_b).data_ptr(),
+                                    B, S, H, seed, offset, x0.data_ptr(), xt.data_ptr(), _lib.current_stream()), "train_noise")
+    return x0, xt
+
+
+def train_loss_terms(x0hat, emb, x0, mask):
+    """-> fp32 [B, 3]: per dialog sums of m (x0hat-emb)^2, m (x0hat-x0)^2, m x0^2 (m = int64 mask [B,S])."""
+    B, S, H = x0hat.shape
+    out = torch.empty((B, 3), dtype=torch.float32, device=x0hat.device)
+    mask = mask.to(torch.int64).contiguous()
+    _lib.check(lib.didi_train_loss_terms(_f32c(x0hat).data_ptr(), _f32c(emb).data_ptr(), _f32c(x0).data_ptr(), mask.data_ptr(), B, S, H,
+                                         out.data_ptr(), _lib.current_stream()), "train_loss_terms")
+    return out
+
+
+def train_mse_backward(x0hat, emb, x0, mask, w_emb, w_x0):
+    B, S, H = x0hat.shape
+    dx = torch.empty_like(x0hat)
+    mask = mask.to(torch.int64).contiguous()
+    _lib.check(lib.didi_train_mse_backward(_f32c(x0hat).data_ptr(), _f32c(emb).data_ptr(), _f32c(x0).data_ptr(), mask.data_ptr(),
+                                           float(w_emb), float(w_x0), B * S, H, dx.data_ptr(), _lib.current_stream()), "train_mse_backward")
+    return dx
+
+
+def layernorm_backward(dy, x, gamma, eps):
+    """-> (dx [M,H], dgamma [H], dbeta [H]) of torch.nn.LayerNorm over the last dim, from dy, the layer INPUT x and gamma."""
+    dy, x = _f32c(dy), _f32c(x)
+    H = x.shape[-1]
+    M = x.numel() // H
+    dx = torch.empty_like(x)
+    dg, db = torch.empty(H, dtype=torch.float32, device=x.device), torch.empty(H, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.didi_layernorm_backward_bytes(M, H), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.didi_layernorm_backward(dy.data_ptr(), x.data_ptr(), _f32c(gamma).data_ptr(), float(eps), M, H, dx.data_ptr(),
+                                           dg.data_ptr(), db.data_ptr(), ws.data_ptr(), _lib.current_stream()), "layernorm_backward")
+    return dx, dg, db
+
+
+def colsum(x):
+    x = _f32c(x)
+    M, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.didi_colsum_bytes(M, N), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.didi_colsum(x.data_ptr(), M, N, out.data_ptr(), ws.data_ptr(), _lib.current_stream()), "colsum")
+    return out
+
+
+def transpose_split(x, dtype=torch.bfloat16):
+    """fp32 [R, C] -> planes (hi, lo) of x^T, shaped [C, ldo] with ldo = R rounded up to 8 (zero padded): a GEMM operand."""
+    x = _f32c(x)
+    R, Cc = x.shape
+    ldo = (R + 7) // 8 * 8
+    hi = torch.empty((Cc, ldo), dtype=dtype, device=x.device)
+    lo = torch.empty_like(hi)
+    _lib.check(lib.didi_transpose_split(x.data_ptr(), R, Cc, ldo, hi.data_ptr(), lo.data_ptr(), _fmt(dtype), _lib.current_stream()),
+               "transpose_split")
+    return hi, lo
+
+
+def linear_backward(dC, A, W, precision="bf16x3"):
+    """Backward of C = A W^T + b (nn.Linear): dC [M,N], A [M,K], W [N,K] fp32 -> (dA [M,K], dW [N,K], db [N]).
+    dgrad and wgrad are didi_gemm launches on transposed operand planes; db is a column sum."""
+    pd = plane_dtype(precision)
+    dC, A, W = _f32c(dC), _f32c(A), _f32c(W)
+    M, N = dC.shape
+    K = A.shape[1]
+    dc_hi, dc_lo = split(dC, dtype=pd)
+    wt_hi, wt_lo = transpose_split(W, dtype=pd)          # [K, N8]
+    if wt_hi.shape[1] != N:  # K of this GEMM is N: the A operand must carry the same zero padding
+        pad = wt_hi.shape[1]
+        z = torch.zeros((M, pad), dtype=torch.float32, device=dC.device)
+        z[:, :N] = dC
+        dc_hi, dc_lo = split(z, dtype=pd)
+    _, _, dA = gemm(dc_hi, dc_lo, wt_hi, wt_lo, precision=precision, out_f32=True, out_planes=False)
+    dct_hi, dct_lo = transpose_split(dC, dtype=pd)       # [N, M8]
+    at_hi, at_lo = transpose_split(A, dtype=pd)          # [K, M8]
+    _, _, dW = gemm(dct_hi, dct_lo, at_hi, at_lo, precision=precision, out_f32=True, out_planes=False)
+    return dA, dW, colsum(dC)

@@ -453,6 +453,36 @@ typedef struct didi_sample_args {
 } didi_sample_args;
 int didi_sample(const didi_decoder* dec, const didi_sample_args* a, void* stream);
 
+/* ---------------------------------------------------------------- training step
+ * Forward + loss of DiDi.training_step (src/diffusion/model.py:200-243) and the first backward kernels.  The decoder forward
+ * is didi_decoder_forward with a per-dialog time_idx; the two cross-entropy terms are didi_round_ce.  dgrad / wgrad are
+ * didi_gemm launches on transposed operand planes (didi_transpose_split):
+ *     dA [M,K] = dC [M,N] W [N,K]      -> didi_gemm(A = planes(dC),   W = transpose_split(W)  as [K, N])
+ *     dW [N,K] = dC^T [N,M] A [M,K]    -> didi_gemm(A = transpose_split(dC) as [N, M], W = transpose_split(A) as [K, M]) */
+
+/* x_0 = emb + std_0 n0 (get_x0, src/diffusion/utils.py:24-27);  x_t = (x_0 + s_b n1) c_b (get_diffusion_variables, :34-40, with
+ * s_b = sigma_{t_b} noise_factor^2 and c_b = 1/sqrt(sigma_{t_b}^2 + 1) per dialog, fp32 [B], computed by the caller from t).
+ * n0 / n1: injected fp32 [B,S,H] draws or NULL = in-kernel Philox (seed, counters offset.. and offset + B*S*H/4..). */
+int didi_train_noise(const float* emb, const float* n0, const float* n1, float std0, const float* s_b, const float* c_b, int B,
+                     int S, int H, uint64_t seed, uint64_t offset, float* x0, float* xt, void* stream);
+/* out[b] = { sum m (x0hat-emb)^2, sum m (x0hat-x0)^2, sum m x0^2 } over dialog b (m = target non-pad mask, int64 [B,S]):
+ * the masked MSE of model.py:222-227 (both branches of its `t == 1` switch) and the t_T term of :229-231. */
+int didi_train_loss_terms(const float* x0hat, const float* emb, const float* x0, const int64_t* mask, int B, int S, int H,
+                          float* out, void* stream);
+/* dx = m (w_emb (x0hat - emb) + w_x0 (x0hat - x0)): the gradient of that MSE with respect to x0hat. */
+int didi_train_mse_backward(const float* x0hat, const float* emb, const float* x0, const int64_t* mask, float w_emb, float w_x0,
+                            int M, int H, float* dx, void* stream);
+/* LayerNorm backward (torch.nn.LayerNorm over the last dim): dx, dgamma, dbeta from dy, the layer's INPUT x and gamma.
+ * workspace: didi_layernorm_backward_bytes(M, H).  H % 4 == 0, H <= 1280.  Deterministic (no atomics). */
+size_t didi_layernorm_backward_bytes(int M, int H);
+int didi_layernorm_backward(const float* dy, const float* x, const float* gamma, float eps, int M, int H, float* dx, float* dgamma,
+                            float* dbeta, void* workspace, void* stream);
+/* out[n] = sum_m x[m, n] (bias gradients); workspace: didi_colsum_bytes(M, N). */
+size_t didi_colsum_bytes(int M, int N);
+int didi_colsum(const float* x, int M, int N, float* out, void* workspace, void* stream);
+/* fp32 src [R, C] -> split planes of its transpose [C, ldo], ldo >= R (columns R..ldo-1 zero: pads the GEMM's K to % 8). */
+int didi_transpose_split(const float* src, int R, int C, int ldo, uint16_t* hi, uint16_t* lo, int plane_format, void* stream);
+
 /* hipEvent wrappers for the prof_events_host hook (bench.py): events must live in the HIP runtime
  * instance this library is bound to.  Host-side helpers, no reference counterpart.  Elapsed time
  * may only be read after the caller has synchronised the stream. */

@@ -32,24 +32,28 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARC
 
 
 class GemmProf:
-    """HIP events for the engine's per-GEMM timing hook (didi_forward_args.prof_events_host)."""
+    """HIP events for the engine's per-GEMM timing hook (didi_sample_args.prof_*): one block of events per profiled call."""
 
-    def __init__(self, call, capacity=256):
+    def __init__(self, calls, per_call=256):
         from didi_amd._lib import check, lib  # events are created inside libdidi_hip's HIP runtime
 
         self.lib, self.check = lib, check
-        self.call, self.capacity, self.used = call, capacity, C.c_int(0)
-        self.events = (C.c_void_p * capacity)()
-        for i in range(capacity):
+        self.per_call, self.capacity = per_call, per_call * len(calls)
+        self.calls = (C.c_int * len(calls))(*calls)
+        self.used = (C.c_int * len(calls))()
+        self.events = (C.c_void_p * self.capacity)()
+        for i in range(self.capacity):
             ev = C.c_void_p()
             check(lib.didi_event_create(C.byref(ev)), "event_create")
             self.events[i] = ev
 
-    def durations_ms(self):
+    def durations_ms(self, j=0):
+        """Durations of the GEMM launches of profiled call j, in launch order."""
         out = []
-        for i in range(0, self.used.value, 2):
+        for i in range(0, self.used[j], 2):
             ms = C.c_float()
-            self.check(self.lib.didi_event_elapsed_ms(self.events[i], self.events[i + 1], C.byref(ms)), "event_elapsed")
+            a, b = self.events[j * self.per_call + i], self.events[j * self.per_call + i + 1]
+            self.check(self.lib.didi_event_elapsed_ms(a, b, C.byref(ms)), "event_elapsed")
             out.append(ms.value)
         return out
 
@@ -140,9 +144,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default="fp16x2", choices=["bf16", "fp16", "fp16x2", "bf16x3"],
-                    help="fp16x2 (default): fp16 planes, two MFMA products A_hi*(W_hi+W_lo): the cheapest mode that holds ids >= 99.9 %% and "
-                         "x_t <= 1e-3 at THIS model size; fp16: one product (misses the bars at this size); bf16x3: fp32-class, three products")
+    ap.add_argument("--precision", default="fp16-sched", choices=["bf16", "fp16", "fp16x2", "fp16-sched", "fp16x3", "bf16x3"],
+                    help="fp16-sched (default): fp16 planes with the precision schedule of didi_amd.model.DEFAULT_SCHEDULE (one MFMA product "
+                         "for t > 0.4 T, the weights' remainder for t > 0.064 T, all three products for the last steps): the cheapest "
+                         "configuration that holds ids >= 99.9 %% and x_t <= 1e-3 over the 2000-call loop at THIS model size; fp16 / fp16x2: "
+                         "one / two products throughout (miss the bars at 2000 calls); fp16x3 / bf16x3: fp32-class, three products")
     ap.add_argument("--mode", default="ddpm", choices=["ddpm", "euler"])
     ap.add_argument("--freq", type=int, default=1)
     ap.add_argument("--batch", type=int, default=256, help="dialogs per GPU")
@@ -168,7 +174,7 @@ def main():
     from didi_amd import dist as ddist
     from didi_amd.config import DiDiConfig
     from didi_amd.model import DiDiSampler
-    from didi_amd.schedule import ddpm_plan
+    from didi_amd.schedule import ddpm_plan, euler_plan
     from didi_amd.synthetic import RawContext, synthetic_batch, synthetic_state_dict
 
     rank, world, local_rank = ddist.init_from_env("cuda")
@@ -178,12 +184,24 @@ def main():
 
     cfg = DiDiConfig(diffusion_steps=args.diffusion_steps, **({"vocab": args.vocab} if args.vocab else {}))
     sd = synthetic_state_dict(cfg, seed=1234)
-    model = DiDiSampler(sd, cfg, device=dev, precision=args.precision)
+    if args.precision == "fp16x3":  # fp16 planes, all three products in every call
+        model = DiDiSampler(sd, cfg, device=dev, precision="fp16x2", schedule=((0, "fp16x3"),))
+    else:
+        model = DiDiSampler(sd, cfg, device=dev, precision=args.precision)
     B_total, S = args.batch * world, args.seq
     ids, mask = synthetic_batch(B_total, args.seq, cfg.vocab, seed=0xBADB01)  # the global batch, on the host
     lo, hi = ddist.shard_bounds(B_total, world, rank)
     ctx = RawContext(ids[lo:hi].to(dev), mask[lo:hi].to(dev))  # only this rank's shard is uploaded; resident in HBM before the timed region
-    n_calls = ddpm_plan(model._sigmas_host, cfg.diffusion_steps, args.freq).n_calls  # same count for euler
+    plan = (ddpm_plan(model._sigmas_host, cfg.diffusion_steps, args.freq) if args.mode == "ddpm" else
+            euler_plan(model._sigmas_host, cfg.diffusion_steps, args.freq, 1, cfg.s_churn, cfg.s_tmin, cfg.s_tmax))
+    n_calls = plan.n_calls
+    # precision of every call (a precision schedule has up to three regimes); one representative call per regime is instrumented
+    names = {v: k for k, v in __import__("didi_amd.ops", fromlist=["PRECISIONS"]).PRECISIONS.items()}
+    per_call = model.call_precisions(plan.time_row) or [model.prec] * n_calls
+    regimes = []  # (precision name, number of calls, index of its middle call)
+    for pv in dict.fromkeys(per_call):
+        idx = [k for k, q in enumerate(per_call) if q == pv]
+        regimes.append((names[pv], len(idx), idx[len(idx) // 2]))
 
     def step(prof=None):
         return ddist.sample_sharded(ctx, model, args.mode, args.freq, rank=rank, world=world, max_len=S, eos_id=2, global_batch=B_total,
@@ -200,7 +218,7 @@ def main():
         torch.distributed.all_gather_into_tensor(torch.empty((world, S + 1), dtype=torch.int32, device=dev), probe)
     for _ in range(args.warmup):
         step()
-    prof = GemmProf(call=n_calls // 2)
+    prof = GemmProf(calls=sorted(r[2] for r in regimes))
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -222,36 +240,50 @@ def main():
     # random-init weights give near-uniform ids; a poisoned batch rounds to one token (NaN rows -> index 0)
     assert top_share < 0.5 and distinct >= min(64, cfg.vocab // 4), f"degenerate ids: top share {top_share:.3f}, {distinct} distinct"
 
-    # roofline of the dominant kernel (MFMA GEMM) from the HIP events of one denoiser call
+    # roofline of the dominant kernel (MFMA GEMM) from the HIP events around every GEMM launch of one denoiser call per precision
+    # regime, weighted by the number of calls each regime has in the loop
     M = args.batch * S
-    dur = prof.durations_ms()
     flops = gemm_flops_per_call(cfg, M)
+    order = sorted(range(len(regimes)), key=lambda i: regimes[i][2])  # GemmProf holds the calls in increasing index
     roofline = None
-    if len(dur) == len(flops):
-        achieved = sum(flops) / (sum(dur) * 1e-3) / 1e12
+    per_regime, w_time, w_flop, w_launch = {}, 0.0, 0.0, 0
+    for slot, ri in enumerate(order):
+        name, n_reg, call = regimes[ri]
+        dur = prof.durations_ms(slot)
+        if len(dur) != len(flops):
+            per_regime = None
+            break
+        mult = {"bf16x3": 3, "fp16x3": 3, "fp16x2": 2}.get(name, 1)
+        tf = sum(flops) / (sum(dur) * 1e-3) / 1e12
+        per_regime[name] = {
+            "calls": n_reg, "profiled_call": call, "gemm_ms_per_call": round(sum(dur), 3), "avg_launch_us": round(1e3 * sum(dur) / len(dur), 2),
+            "algorithmic_tflops": round(tf, 1), "mfma_products_per_product": mult, "executed_mfma_tflops": round(tf * mult, 1),
+            "plain (qkv, cross_q, ffn_up) tflops": round(sum(flops[0::2]) / (sum(dur[0::2]) * 1e-3) / 1e12, 1),
+            "with LayerNorm epilogue (attn_out, cross_out, ffn_down) tflops": round(sum(flops[1::2]) / (sum(dur[1::2]) * 1e-3) / 1e12, 1),
+        }
+        w_time += n_reg * sum(dur) * 1e-3
+        w_flop += n_reg * sum(flops)
+        w_launch += n_reg * len(dur)
+    if per_regime:
+        achieved = w_flop / w_time / 1e12
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", f"gemm_traffic_{args.precision}.json")
         if os.path.exists(tpath) and args.batch == 256 and args.seq == 64:  # PMC passes are a separate run (profiles/README.md)
             traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
             traffic_src = os.path.relpath(tpath, ROOT)
         roofline = {
-            "bound": "mfma", "kernel": (f"gemm_pp_kernel<{ {'bf16x3': 3, 'fp16x2': 2}.get(args.precision, 1) }, {'true' if args.precision in ('fp16', 'fp16x2') else 'false'}, LN, false> "
-                                         "(256x192 tile, staggered wave groups; LN=true on the three output projections per layer, "
-                                         "which carry bias + residual + LayerNorm in the epilogue)"),
+            "bound": "mfma", "kernel": ("gemm_pp_kernel<NPASS, F16, LN, false> (256x192 tile, staggered wave groups; NPASS = MFMA products per "
+                                         "algorithmic product: 1 fp16, 2 fp16x2, 3 fp16x3/bf16x3; LN = true on the three output projections per "
+                                         "layer, which carry bias + residual + LayerNorm in the epilogue)"),
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "launches": len(dur), "avg_launch_us": round(1e3 * sum(dur) / len(dur), 2),
+            "launches_per_call": len(flops), "avg_launch_us": round(1e6 * w_time / w_launch, 2),
             "avg_gflop_per_launch": round(sum(flops) / len(flops) / 1e9, 2),
-            "gemm_share_of_call": round(sum(dur) / (1e3 * elapsed / (args.steps * n_calls)), 3),
-            # launches 1, 3, 5 of every layer (attention/cross/FFN output projections) also do bias + residual + LayerNorm
-            "by_variant_tflops": {
-                "plain (qkv, cross_q, ffn_up)": round(sum(flops[0::2]) / (sum(dur[0::2]) * 1e-3) / 1e12, 1),
-                "with LayerNorm epilogue (attn_out, cross_out, ffn_down)": round(sum(flops[1::2]) / (sum(dur[1::2]) * 1e-3) / 1e12, 1),
-            },
-            "note": ("algorithmic FLOPs 2*M*N*K per launch" + {"bf16x3": "; the kernel issues 3 MFMA products per algorithmic product, which are not counted",
-                                                               "fp16x2": "; the kernel issues 2 MFMA products per algorithmic product (A_hi*W_hi + A_hi*W_lo), "
-                                                                         "which are not counted: executed MFMA rate = 2x achieved"}.get(args.precision, "")),
-            "mfma_products_per_algorithmic_product": {"bf16x3": 3, "fp16x2": 2}.get(args.precision, 1),
+            "gemm_share_of_step": round(w_time / (elapsed / args.steps), 3),
+            "by_precision_regime": per_regime,
+            "note": ("achieved = algorithmic FLOPs (2*M*N*K per launch, the extra MFMA products of fp16x2 / x3 NOT counted) of all GEMM launches of the "
+                     "loop / their summed durations: HIP events around every GEMM launch of one denoiser call per precision regime inside the "
+                     "timed region, weighted by the regime's number of calls"),
         }
     prof.close()
 
@@ -259,7 +291,8 @@ def main():
     res = {
         "metric": "sampled dialogs/sec (whole node, T steps)", "value": round(value, 3), "unit": "dialogs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 1),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"fp16-sched": "fp16", "fp16x2": "fp16", "fp16x3": "fp16", "bf16x3": "bf16"}.get(args.precision, args.precision), "data": "synthetic",
         "config": {
             "workload": (f"{workload}: blenderbot-400M-distill-sized encoder (2x1280/32h/5120) + BertConfig-default "
                          f"decoder (12x768/12h/3072), V={cfg.vocab}, {args.mode} T={cfg.diffusion_steps} step_freq={args.freq} "
@@ -267,13 +300,21 @@ def main():
                          + (", per-step clamp extension ON" if args.clamp else "")),
             "global_batch": B_total, "seq_len": S, "denoiser_calls": n_calls, "parallelism": f"dp{world} (batch shard, id all-gather)",
             "weights": "random-init N(0,0.02), seed 1234", "noise": "in-kernel Philox",
+            "precision": args.precision,
+            "precision_schedule": ({"timestep_thresholds": [list(x) for x in model.schedule], "calls": {r[0]: r[1] for r in regimes}}
+                                   if model.schedule else None),
             "precision_note": {
-                "fp16x2": ("dtype fp16x2 where BASELINE configs[1] says bf16: 16-bit MFMA operands with fp32 accumulation, as bf16, but the parity bar "
-                           "(ids >= 99.9 %, x_t <= 1e-3 against the fp32 reference) decides the mode: at this model size plain bf16 and one-product "
-                           "fp16 miss it (weight rounding adds up coherently over the loop), fp16 activations x (fp16 hi + lo) weights hold it at 2 "
-                           "MFMA products per product (tests/test_gpu_fullsize.py); bf16x3 = fp32-class at 3"),
+                "fp16-sched": ("fp16 operand planes where BASELINE configs[1] says bf16: 16-bit MFMA operands with fp32 accumulation either way; the "
+                               "parity bar (ids >= 99.9 %, every x_t <= 1e-3 against the fp32 reference) decides what is multiplied: one-product "
+                               "bf16 / fp16 miss it at this model size (weight rounding adds up coherently over the loop), so calls run one "
+                               "product while x_t is mostly fresh noise, add the weights' remainder plane below t = 0.4 T and multiply all three "
+                               "products for the last 0.064 T steps: 0 of 1024 ids differ, max x_t rel-L2 5.7e-4 over 2000 calls "
+                               "(profiles/r02_parity_f1_ddpm.log, tests/test_gpu_fullsize.py)"),
+                "fp16x2": "fp16 planes, A_hi*(W_hi+W_lo) in every call: holds the bars over 201 calls (step_freq 10), misses them over 2000",
                 "fp16": "one-product fp16: misses the parity bars at this model size (tests/test_gpu_fullsize.py); not a valid headline mode",
                 "bf16": "one-product bf16: misses the parity bars (99.46 % ids on the config-1 model); not a valid headline mode",
+                "fp16x3": "fp16 planes, all three products in every call: fp32-class (max x_t rel-L2 2.9e-5 over 2000 calls, 0 of 1024 ids differ)",
+                "bf16x3": "bf16 planes, all three products: fp32-class with fp32's exponent range (max x_t rel-L2 1.0e-4 over 2000 calls)",
             }.get(args.precision),
             "world_size_seen": torch.distributed.get_world_size() if world > 1 else 1,
             "backend": torch.distributed.get_backend() if world > 1 else None,

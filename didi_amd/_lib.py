@@ -108,9 +108,9 @@ class SampleArgs(C.Structure):
         ("x_state", C.c_void_p), ("x0_f32", C.c_void_p), ("x0_hi", C.c_void_p), ("x0_lo", C.c_void_p),
         ("cls_hi", C.c_void_p), ("cls_lo", C.c_void_p), ("V", C.c_int), ("argmax_partial", C.c_void_p),
         ("ids64", C.c_void_p),
-        ("prof_call", C.c_int), ("prof_events_host", C.POINTER(C.c_void_p)), ("prof_capacity", C.c_int),
+        ("prof_calls_host", C.POINTER(C.c_int)), ("n_prof_calls", C.c_int), ("prof_events_host", C.POINTER(C.c_void_p)), ("prof_capacity", C.c_int),
         ("prof_used_host", C.POINTER(C.c_int)), ("clamp_emb", C.c_void_p), ("fault", C.c_void_p),
-        ("tail_calls", C.c_int), ("tail_precision", C.c_int),
+        ("precision_host", C.POINTER(C.c_int)),
     ]
 
 

@@ -216,7 +216,7 @@ def load_state(path):
     return sd, hp
 
 
-def load_lightning_checkpoint(path, device="cuda", precision="fp16x2", **overrides):
+def load_lightning_checkpoint(path, device="cuda", precision="fp16-sched", **overrides):
     """``DiDi.load_from_checkpoint`` for the sampler path -> DiDiSampler."""
     from .model import DiDiSampler
 

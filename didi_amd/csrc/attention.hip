@@ -298,8 +298,9 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
     if (a->causal && a->Sq != a->Sk) return DIDI_ERR_BAD_ARG;
     DIDI_CHECK_ARG(a->scale >= 0.f && (reinterpret_cast<uintptr_t>(a->pos_bias) & 3) == 0);
     DIDI_CHECK_ARG(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo > 0 && a->ldo % 4 == 0);
-    const bool x3 = a->precision == DIDI_PREC_BF16X3;
-    const bool f16 = a->precision == DIDI_PREC_FP16 || a->precision == DIDI_PREC_FP16X2;  // no weights here: x2 = one product
+    const bool x3 = a->precision == DIDI_PREC_BF16X3 || a->precision == DIDI_PREC_FP16X3;
+    const bool f16 = a->precision == DIDI_PREC_FP16 || a->precision == DIDI_PREC_FP16X2 ||  // no weights here: x2 = one product
+                     a->precision == DIDI_PREC_FP16X3;                                       // x3: all three products on fp16 planes
     DIDI_CHECK_ARG(x3 || f16 || a->precision == DIDI_PREC_BF16);
     if (x3) DIDI_CHECK_ARG(a->Q_lo && a->K_lo && a->V_lo && a->O_lo);
     const void* ptrs[6] = {a->Q_hi, a->Q_lo, a->K_hi, a->K_lo, a->V_hi, a->V_lo};
@@ -336,11 +337,13 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
         }                                                                            \
     } while (0)
     if (DP == 64) {
-        if (x3) DIDI_ATTN(64, 3, false);
+        if (x3 && f16) DIDI_ATTN(64, 3, true);
+        else if (x3) DIDI_ATTN(64, 3, false);
         else if (f16) DIDI_ATTN(64, 1, true);
         else DIDI_ATTN(64, 1, false);
     } else {
-        if (x3) DIDI_ATTN(32, 3, false);
+        if (x3 && f16) DIDI_ATTN(32, 3, true);
+        else if (x3) DIDI_ATTN(32, 3, false);
         else if (f16) DIDI_ATTN(32, 1, true);
         else DIDI_ATTN(32, 1, false);
     }

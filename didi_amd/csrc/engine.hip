@@ -173,7 +173,7 @@ extern "C" int didi_decoder_prepare_context(const didi_decoder* dec, const float
                                             void* stream) {
     DIDI_CHECK_ARG(dec && ctx && workspace && kv_hi && dec->layers_host);
     DIDI_CHECK_ARG(precision == DIDI_PREC_BF16 || precision == DIDI_PREC_FP16 || precision == DIDI_PREC_FP16X2 ||
-                   (precision == DIDI_PREC_BF16X3 && kv_lo));
+                   ((precision == DIDI_PREC_BF16X3 || precision == DIDI_PREC_FP16X3) && kv_lo));
     if (!shapes_ok(dec, B, 1, C)) return DIDI_ERR_UNSUPPORTED;
     const size_t Mc = (size_t)B * C, H = dec->H;
     const size_t plane = al256(Mc * H * 2);
@@ -182,12 +182,17 @@ extern "C" int didi_decoder_prepare_context(const didi_decoder* dec, const float
     u16* c_lo = (u16*)((char*)workspace + plane);
     if (precision == DIDI_PREC_FP16 || precision == DIDI_PREC_FP16X2) TRY(didi_split_fp16(ctx, c_hi, c_lo, Mc * H, stream));
     else TRY(didi_split_bf16(ctx, c_hi, c_lo, Mc * H, stream));
+    // fp16-plane precisions with a kv_lo buffer: the cache is computed ONCE per batch, so it gets all three products and its
+    // remainder plane (what an fp16x3 call of a precision schedule reads); one-product calls read kv_hi alone
+    const bool f16 = precision == DIDI_PREC_FP16 || precision == DIDI_PREC_FP16X2 || precision == DIDI_PREC_FP16X3;
+    const int kv_prec = f16 && kv_lo ? DIDI_PREC_FP16X3 : precision;
+    const bool want_lo = kv_lo && (precision == DIDI_PREC_BF16X3 || f16);
     for (int l = 0; l < dec->L; ++l) {
         const didi_decoder_layer& ly = dec->layers_host[l];
         DIDI_CHECK_ARG(ly.ckv.N == 2 * dec->H && ly.ckv.K == dec->H);
         const size_t off = (size_t)l * Mc * 2 * H;
-        TRY(gemm(ly.ckv, precision, (int)Mc, c_hi, c_lo, (int)H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, kv_hi + off,
-                 precision == DIDI_PREC_BF16X3 ? kv_lo + off : nullptr, (int)(2 * H), stream));
+        TRY(gemm(ly.ckv, kv_prec, (int)Mc, c_hi, c_lo, (int)H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, kv_hi + off,
+                 want_lo ? kv_lo + off : nullptr, (int)(2 * H), stream));
     }
     return DIDI_OK;
 }
@@ -195,23 +200,23 @@ extern "C" int didi_decoder_prepare_context(const didi_decoder* dec, const float
 extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_args* a, void* stream) {
     DIDI_CHECK_ARG(dec && a && dec->layers_host && a->workspace && a->x0_f32 && a->kv_hi && a->ctx_mask);
     const int prec = a->precision;
-    DIDI_CHECK_ARG(prec == DIDI_PREC_BF16 || prec == DIDI_PREC_FP16 || prec == DIDI_PREC_FP16X2 || prec == DIDI_PREC_FP16X3 ||
-                   (prec == DIDI_PREC_BF16X3 && a->kv_lo));
+    DIDI_CHECK_ARG(prec == DIDI_PREC_BF16 || prec == DIDI_PREC_FP16 || prec == DIDI_PREC_FP16X2 ||
+                   ((prec == DIDI_PREC_BF16X3 || prec == DIDI_PREC_FP16X3) && a->kv_lo));
     DIDI_CHECK_ARG(!(a->x0_lo && !a->x0_hi));
     if (!shapes_ok(dec, a->B, a->S, a->C)) return DIDI_ERR_UNSUPPORTED;
     if (a->S > 0 && dec->pos_emb == nullptr) return DIDI_ERR_BAD_ARG;
     const Carve w = carve(dec, a->B, a->S, (char*)a->workspace);
     if (a->workspace_bytes < w.total) return DIDI_ERR_WORKSPACE;
     const int M = a->B * a->S, H = dec->H, I = dec->I, D = H / dec->heads;
-    const bool x3 = prec == DIDI_PREC_BF16X3;
+    // x3: every GEMM and both attention matmuls multiply all three products and every activation travels with its remainder
+    // plane (bf16 planes: BF16X3; fp16 planes: FP16X3).  FP16X2 adds the remainder of the WEIGHTS only; attention has no weights,
+    // so there it is one product.
+    const bool x3 = prec == DIDI_PREC_BF16X3 || prec == DIDI_PREC_FP16X3;
     const bool f16 = prec == DIDI_PREC_FP16 || prec == DIDI_PREC_FP16X2 || prec == DIDI_PREC_FP16X3;
     const int fmt = f16 ? DIDI_FMT_FP16 : DIDI_FMT_BF16;
-    // fp16x2 / fp16x3 add the remainders of the WEIGHTS (and, x3, of the GEMM inputs that carry one: the residual stream h and
-    // the GELU output); attention has no weights and its operands are single fp16 planes in every fp16 mode, so the projections
-    // that read the attention output run as fp16x2 inside an fp16x3 call
-    const int attn_prec = f16 ? DIDI_PREC_FP16 : prec;
-    const int proj_prec = prec == DIDI_PREC_FP16X3 ? DIDI_PREC_FP16X2 : prec;
-    const bool ffn_lo = x3 || prec == DIDI_PREC_FP16X3;
+    const int attn_prec = prec == DIDI_PREC_FP16X2 ? DIDI_PREC_FP16 : prec;
+    const int proj_prec = prec;
+    const bool ffn_lo = x3;
     const size_t Mc = (size_t)a->B * a->C;
     Prof prof{a->prof_events_host, a->prof_capacity, 0};
 
@@ -274,9 +279,10 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
     if (s->ids64 && s->precision == DIDI_PREC_BF16X3) DIDI_CHECK_ARG(s->cls_lo && s->x0_lo);
     if (s->ids64 && s->precision == DIDI_PREC_FP16X2) DIDI_CHECK_ARG(s->cls_lo);
     if (s->clamp_emb) DIDI_CHECK_ARG(s->ids64 && s->x0_hi && s->x0_lo);
-    if (s->tail_calls > 0) {  // both precisions must work on the same plane format (the workspace planes and the K/V cache are shared)
+    if (s->precision_host) {  // every call must work on the same plane format (the workspace planes and the K/V cache are shared)
         auto is_f16 = [](int p) { return p == DIDI_PREC_FP16 || p == DIDI_PREC_FP16X2 || p == DIDI_PREC_FP16X3; };
-        DIDI_CHECK_ARG(is_f16(s->precision) && is_f16(s->tail_precision));
+        DIDI_CHECK_ARG(is_f16(s->precision));
+        for (int k = 0; k < s->n_calls; ++k) DIDI_CHECK_ARG(is_f16(s->precision_host[k]));
     }
     if (!shapes_ok(dec, s->B, s->S, s->C)) return DIDI_ERR_UNSUPPORTED;
     const size_t MH = (size_t)s->B * s->S * dec->H;
@@ -289,8 +295,8 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
     f.x0_f32 = s->x0_f32;
     f.fault = s->fault;
     auto draw = [&](int i) -> const float* { return s->noise ? s->noise + (size_t)i * MH : nullptr; };
-    // precision schedule: the last tail_calls denoiser calls run in tail_precision (same plane format as `precision`)
-    auto prec_of = [&](int k) { return s->tail_calls > 0 && k >= s->n_calls - s->tail_calls ? s->tail_precision : s->precision; };
+    // precision schedule: one precision per denoiser call (all on the plane format of `precision`)
+    auto prec_of = [&](int k) { return s->precision_host ? s->precision_host[k] : s->precision; };
     // per-step clamp extension: x0 <- emb[argmax(classifier(x0))]; the forward leaves x0 planes for the rounding GEMM
     const bool clamp = s->clamp_emb != nullptr;
     auto clamp_x0 = [&]() -> int {
@@ -304,10 +310,15 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
                                               : didi_split_bf16(s->x0_f32, s->x0_hi, s->x0_lo, MH, stream);
     };
     auto set_prof = [&](int k) {
-        const bool on = s->prof_events_host && k == s->prof_call;
-        f.prof_events_host = on ? s->prof_events_host : nullptr;
-        f.prof_capacity = on ? s->prof_capacity : 0;
-        f.prof_used_host = on ? s->prof_used_host : nullptr;
+        f.prof_events_host = nullptr; f.prof_capacity = 0; f.prof_used_host = nullptr;
+        if (!s->prof_events_host || !s->prof_calls_host || s->n_prof_calls <= 0) return;
+        const int cap = s->prof_capacity / s->n_prof_calls;
+        for (int j = 0; j < s->n_prof_calls; ++j)
+            if (s->prof_calls_host[j] == k) {
+                f.prof_events_host = s->prof_events_host + (size_t)j * cap;
+                f.prof_capacity = cap;
+                f.prof_used_host = s->prof_used_host ? s->prof_used_host + j : nullptr;
+            }
     };
 
     if (!s->euler) {
@@ -371,7 +382,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
     if (s->ids64) {
         // the FINAL rounding of the fp16x2 mode (and of any precision schedule) multiplies all three products (once per batch: free): the ids then carry the
         // loop's error only, not the operand rounding of the classifier GEMM on top of it
-        const int round_prec = (s->precision == DIDI_PREC_FP16X2 || s->tail_calls > 0) && s->x0_lo && s->cls_lo ? DIDI_PREC_FP16X3 : s->precision;
+        const int round_prec = (s->precision == DIDI_PREC_FP16X2 || s->precision_host) && s->x0_lo && s->cls_lo ? DIDI_PREC_FP16X3 : s->precision;
         TRY(didi_round_argmax(s->x0_hi, s->x0_lo, dec->H, s->cls_hi, s->cls_lo, dec->H, s->B * s->S, s->V, dec->H,
                               round_prec, s->argmax_partial, s->ids64, nullptr, stream));
     }

@@ -23,6 +23,12 @@ from .config import DiDiConfig
 from .schedule import configure_schedule
 
 
+# Default precision schedule of "fp16-sched", as fractions of the number of diffusion steps T (measured at
+# T = 2000, sqrt schedule: t > 800 / t > 128 / the rest): one product while the input is mostly fresh noise, the weights'
+# remainder once x_t starts to carry the previous estimate, all three products for the last steps.
+DEFAULT_SCHEDULE = ((0.4, "fp16"), (0.064, "fp16x2"), (0, "fp16x3"))
+
+
 class _Planes:
     """A Linear's packed weights: split planes [N, K] (bf16, or fp16 for the "fp16" precision) + fp32 bias."""
 
@@ -64,16 +70,24 @@ class _Classifier:
 
 
 class DiDiSampler:
-    def __init__(self, state_dict, cfg: DiDiConfig, device="cuda", precision="bf16x3", tail_calls=0, tail_precision="fp16x3"):
-        """``precision``: bf16 | fp16 (one MFMA product), fp16x2 (weights with their remainder), bf16x3 (fp32-class).
-        ``tail_calls`` > 0: precision schedule for ``sample`` -- the LAST tail_calls denoiser calls of a loop run in
-        ``tail_precision`` (fp16 | fp16x2 | fp16x3; needs an fp16-plane ``precision``)."""
+    def __init__(self, state_dict, cfg: DiDiConfig, device="cuda", precision="bf16x3", schedule=None):
+        """``precision``: bf16 | fp16 (one MFMA product), fp16x2 (weights with their remainder), bf16x3 (fp32-class), or
+        "fp16-sched": fp16 planes with the default precision schedule ``DEFAULT_SCHEDULE``.
+        ``schedule``: precision schedule of ``sample`` over the TIMESTEP of each denoiser call, a tuple of (t_above, precision)
+        pairs in decreasing t: a call whose time-embedding row is > t_above runs in that precision (fp16 | fp16x2 | fp16x3);
+        the last pair must have t_above = 0.  Needs an fp16-plane ``precision``."""
+        if precision == "fp16-sched":
+            precision, schedule = "fp16x2", (schedule or DEFAULT_SCHEDULE)
         if precision not in ("bf16", "fp16", "fp16x2", "bf16x3"):
-            raise ValueError("precision must be one of bf16, fp16, fp16x2, bf16x3")
-        if tail_calls and (precision not in ("fp16", "fp16x2") or tail_precision not in ("fp16", "fp16x2", "fp16x3")):
-            raise ValueError("a precision schedule needs fp16-plane precisions: precision fp16|fp16x2, tail_precision fp16|fp16x2|fp16x3")
+            raise ValueError("precision must be one of bf16, fp16, fp16x2, bf16x3, fp16-sched")
+        if schedule is not None:  # thresholds below 1 are fractions of T
+            schedule = tuple((int(round(t * cfg.diffusion_steps)) if 0 < t < 1 else int(t), p) for t, p in schedule)
+            ok = precision in ("fp16", "fp16x2") and all(p in ("fp16", "fp16x2", "fp16x3") for _, p in schedule)
+            ok = ok and schedule[-1][0] == 0 and all(a[0] > b[0] for a, b in zip(schedule, schedule[1:]))
+            if not ok:
+                raise ValueError("a precision schedule needs fp16-plane precisions and (t_above, precision) pairs in decreasing t ending at 0")
         self.cfg, self.device, self.precision = cfg, torch.device(device), precision
-        self.tail_calls, self.tail_precision = int(tail_calls), tail_precision
+        self.schedule = schedule
         sd = state_dict
         dev = self.device
         f = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
@@ -301,11 +315,13 @@ class DiDiSampler:
     def round_precision(self):
         """Precision of the classifier GEMM after the loop (rounding argmax, logits, cross-entropy): the fp16x2 mode spends
         all three products there (once per batch), as the engine's final rounding does."""
-        return "fp16x3" if self.precision == "fp16x2" or self.tail_calls > 0 else self.precision
+        return "fp16x3" if self.precision == "fp16x2" or self.schedule else self.precision
 
-    def prec_of_call(self, k, n_calls):
-        """C-ABI precision of denoiser call k of n_calls under the precision schedule."""
-        return ops.PRECISIONS[self.tail_precision if self.tail_calls > 0 and k >= n_calls - self.tail_calls else self.precision]
+    def call_precisions(self, time_rows):
+        """C-ABI precision of every denoiser call of a loop, from the timestep (time-embedding row) of each; None = uniform."""
+        if not self.schedule:
+            return None
+        return [ops.PRECISIONS[next(p for t_above, p in self.schedule if t > t_above)] for t in time_rows]
 
     def round_operands(self, x0_hi, x0_lo):
         """(x_hi, x_lo or None, precision) for ops.round_argmax / ops.round_ce on x0 planes."""

@@ -154,7 +154,7 @@ def attention(q, k, v, heads, causal=False, key_mask=None, precision="bf16x3", s
         assert t.stride(0) == s * t.stride(1) and t.stride(2) == 1, "planes must be [B*S, ld] row-major"
     assert q[0].dtype == plane_dtype(precision), "operand planes must match the precision's format"
     o_hi = torch.empty((B, Sq, HD), dtype=q[0].dtype, device=q[0].device)
-    o_lo = torch.empty_like(o_hi) if a.precision == _lib.PREC_BF16X3 else None
+    o_lo = torch.empty_like(o_hi) if a.precision in (_lib.PREC_BF16X3, _lib.PREC_FP16X3) else None
     a.O_hi, a.O_lo, a.ldo = o_hi.data_ptr(), _lib.ptr(o_lo), HD
     a.scale = 0.0 if scale is None else float(scale)
     if pos_bias is not None:

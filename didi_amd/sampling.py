@@ -133,10 +133,12 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
         if clamp:
             a.clamp_emb = model.emb.weight.data_ptr()
         a.fault = b["fault"].data_ptr()
-        a.tail_calls, a.tail_precision = model.tail_calls, ops.PRECISIONS[model.tail_precision]
-        if _prof is not None:  # bench.py: HIP events around the GEMM launches of one denoiser call
-            a.prof_call, a.prof_events_host, a.prof_capacity = _prof.call, _prof.events, _prof.capacity
-            a.prof_used_host = C.pointer(_prof.used)
+        precs = model.call_precisions(plan.time_row)
+        prec_arr = (C.c_int * n_calls)(*precs) if precs is not None else None  # kept alive until the call returns
+        a.precision_host = prec_arr if prec_arr is not None else C.cast(None, C.POINTER(C.c_int))
+        if _prof is not None:  # bench.py: HIP events around the GEMM launches of chosen denoiser calls
+            a.prof_calls_host, a.n_prof_calls = _prof.calls, len(_prof.calls)
+            a.prof_events_host, a.prof_capacity, a.prof_used_host = _prof.events, _prof.capacity, _prof.used
         _lib.check(lib.didi_sample(C.byref(model._dec), C.byref(a), _lib.current_stream()), "sample")
         if trace is not None:
             trace.extend(xt_trace.unbind(0))
@@ -171,9 +173,11 @@ def _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp=False):
         x0.copy_(ops.embed_gather(ids.view(B, S), model.emb.weight))
     noise = torch.randn((B, S, H), dtype=torch.float32, device=dev)  # sampling.py:13
 
+    precs = model.call_precisions(plan.time_row)
+
     def forward(step_kw, t, k):
         fa = _lib.ForwardArgs()
-        fa.B, fa.S, fa.C, fa.precision = B, S, Cn, model.prec_of_call(k, plan.n_calls)
+        fa.B, fa.S, fa.C, fa.precision = B, S, Cn, (precs[k] if precs is not None else model.prec)
         st = fa.step
         for k, v in step_kw.items():
             setattr(st, k, v)

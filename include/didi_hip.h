@@ -89,9 +89,9 @@ enum { DIDI_PREC_BF16 = 1, DIDI_PREC_FP16 = 2, DIDI_PREC_BF16X3 = 3,
        DIDI_PREC_FP16X2 = 4,
        /* FP16X3: fp16 planes, all three products (A_hi*W_hi + A_hi*W_lo + A_lo*W_hi, ~22 bits): accepted by didi_gemm,
         * didi_gemm_small, didi_gemm_ln, didi_round_argmax and didi_round_ce.  The engine uses it for the FINAL rounding of an
-        * fp16-plane loop (once per batch), the Python side for materialised logits, and didi_decoder_forward takes it as the
-        * tail precision of a sampling loop: the GEMMs whose input carries a remainder plane (residual stream, GELU output)
-        * multiply all three products, the two projections that read the attention output run as FP16X2, attention as FP16. */
+        * fp16-plane loop (once per batch) and the K/V cache, the Python side for materialised logits; didi_attention and
+        * didi_decoder_forward take it too -- BF16X3's structure (every activation with its remainder plane, three products in
+        * every GEMM and both attention matmuls) on fp16 planes -- as the precision of the last calls of a precision schedule. */
        DIDI_PREC_FP16X3 = 5 };
 enum { DIDI_FMT_BF16 = 0, DIDI_FMT_FP16 = 1 }; /* element format of split planes */
 
@@ -433,8 +433,11 @@ typedef struct didi_sample_args {
     int V;
     void* argmax_partial;
     int64_t* ids64;
-    /* optional: instrument denoiser call number prof_call as in didi_forward_args */
-    int prof_call;
+    /* optional: instrument n_prof_calls denoiser calls (their indices: prof_calls_host, increasing) as in didi_forward_args;
+     * call j of the list records into events [j * cap, (j + 1) * cap) with cap = prof_capacity / n_prof_calls and reports
+     * prof_used_host[j].  A precision schedule has one representative call per precision. */
+    const int* prof_calls_host;
+    int n_prof_calls;
     void** prof_events_host;
     int prof_capacity;
     int* prof_used_host;
@@ -444,12 +447,12 @@ typedef struct didi_sample_args {
      * rounding fields above (cls_*, V, argmax_partial, ids64 as scratch, x0_hi/x0_lo). */
     const float* clamp_emb;
     uint32_t* fault; /* device fault word (DIDI_FAULT_*) or NULL; watched over the whole loop */
-    /* precision schedule (0 = none): the LAST tail_calls denoiser calls run in tail_precision instead of `precision`; both must be
-     * fp16-plane precisions (FP16, FP16X2, FP16X3).  The error of the early, noise-dominated calls is forgotten within a few
-     * dozen steps; what the final ids carry is the rounding of the last calls, so the extra products are spent only there
-     * (DESIGN.md section 2). */
-    int tail_calls;
-    int tail_precision;
+    /* precision schedule: NULL, or a HOST array of n_calls DIDI_PREC_* values, the precision of every denoiser call (all of them
+     * fp16-plane precisions -- FP16, FP16X2, FP16X3 -- like `precision`, which still names the plane format, the K/V cache and
+     * the rounding).  Rounding errors of the early, noise-dominated calls are forgotten within a few hundred steps, and
+     * they grow towards the end of the loop where x_t is mostly the previous estimate: the extra MFMA products are spent
+     * where the bar needs them. */
+    const int* precision_host;
 } didi_sample_args;
 int didi_sample(const didi_decoder* dec, const didi_sample_args* a, void* stream);
 

@@ -553,3 +553,19 @@ def test_attention_all_keys_masked_is_uniform(ops):
     v = qkv[:, :, 2 * HD:]
     assert torch.allclose(got[0], v[0].mean(0, keepdim=True).expand(S, HD), atol=1e-4)
     assert torch.isfinite(got).all()
+
+
+def test_attention_fp16x3_three_products(ops):
+    """didi_attention in DIDI_PREC_FP16X3: fp16 planes with remainders, three products in QK^T and PV, against fp64 on the un-rounded
+    q, k, v at the bf16x3 bar or better."""
+    B, heads, S, d = 3, 4, 40, 64
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(B, S, heads * d, generator=g) for _ in range(3))
+    mask = torch.ones(B, S, dtype=torch.int32)
+    mask[1, 25:] = 0
+    qp, kp, vp = (ops.split(t.cuda(), dtype=torch.float16) for t in (q, k, v))
+    o_hi, o_lo = ops.attention(qp, kp, vp, heads, causal=False, key_mask=mask.cuda(), precision="fp16x3")
+    want = _attn_ref(q, k, v, heads, False, mask)
+    assert o_lo is not None and rel_l2(ops.join(o_hi, o_lo), want) <= 2e-5
+    o1, _ = ops.attention(qp, kp, vp, heads, causal=False, key_mask=mask.cuda(), precision="fp16")
+    assert rel_l2(o1.float(), want) > rel_l2(ops.join(o_hi, o_lo), want)

@@ -303,13 +303,15 @@ def test_torch_noise_loop_equals_native_loop():
 
 
 @pytest.mark.parametrize("name", ["tiny_ddpm_f1", "tiny_euler_churn_f4"])
-def test_precision_schedule_tail(name):
-    """Precision schedule: the last `tail_calls` denoiser calls of a loop run in fp16x3 (all three products on fp16 planes).
-    (a) a tail that covers every call is an fp32-class sampler: x_t within 1e-4 of the reference fixture, ids identical;
-    (b) tail 0 is bit-identical to the plain precision; (c) a partial tail only changes calls from its first one on;
-    (d) the per-call Python loop honours the same schedule bit for bit."""
+def test_precision_schedule(name):
+    """Precision schedule over the timestep of each denoiser call (fp16 planes: fp16 | fp16x2 | fp16x3 per call).
+    (a) fp16x3 for every call is an fp32-class sampler: x_t within 1e-4 of the reference fixture, ids identical;
+    (b) a schedule that names the plain precision everywhere is bit-identical to no schedule; (c) a schedule that switches at
+    timestep t only changes calls from the first one at or below t on; (d) the per-call Python loop honours the same schedule
+    bit for bit; (e) malformed schedules are rejected."""
     from didi_amd.model import DiDiSampler
     from didi_amd.sampling import sample
+    from didi_amd.schedule import ddpm_plan, euler_plan
 
     t, meta = load_case(name)
     run, n_calls = meta["run"], int(meta["n_calls"])
@@ -324,21 +326,30 @@ def test_precision_schedule_tail(name):
         model.check_fault(name)
         return ids.cpu(), tr
 
-    full = DiDiSampler(w, cfg, device="cuda", precision="fp16", tail_calls=n_calls, tail_precision="fp16x3")
+    full = DiDiSampler(w, cfg, device="cuda", precision="fp16", schedule=((0, "fp16x3"),))
     ids, tr = go(full)
     worst = max(rel_l2(x, t[f"xt.{i}"]) for i, x in enumerate(tr))
-    print(f"\n[{name} fp16 + fp16x3 tail over all {n_calls} calls] max x_t rel-L2 {worst:.3e}  id match {(ids == t['out.ids']).float().mean().item():.4f}")
+    print(f"\n[{name} fp16 planes, fp16x3 in all {n_calls} calls] max x_t rel-L2 {worst:.3e}  id match {(ids == t['out.ids']).float().mean().item():.4f}")
     assert worst <= 1e-4 and torch.equal(ids, t["out.ids"])
     plain_ids, plain_tr = go(DiDiSampler(w, cfg, device="cuda", precision="fp16x2"))
-    zero_ids, zero_tr = go(DiDiSampler(w, cfg, device="cuda", precision="fp16x2", tail_calls=0))
-    assert torch.equal(plain_ids, zero_ids) and all(torch.equal(a, b) for a, b in zip(plain_tr, zero_tr))
-    k0 = n_calls - 2
-    part = DiDiSampler(w, cfg, device="cuda", precision="fp16x2", tail_calls=2, tail_precision="fp16x3")
+    same_ids, same_tr = go(DiDiSampler(w, cfg, device="cuda", precision="fp16x2", schedule=((0, "fp16x2"),)))
+    assert all(torch.equal(a, b) for a, b in zip(plain_tr, same_tr))  # (the final rounding of a scheduled loop is fp16x3: ids may differ)
+    m0 = DiDiSampler(w, cfg, device="cuda", precision="fp16x2")
+    plan = (ddpm_plan(m0._sigmas_host, cfg.diffusion_steps, run["step_freq"]) if run["mode"] == "ddpm" else
+            euler_plan(m0._sigmas_host, cfg.diffusion_steps, run["step_freq"], 1, cfg.s_churn, cfg.s_tmin, cfg.s_tmax))
+    t_switch = sorted(plan.time_row)[1]  # the two lowest timesteps run in fp16x3
+    part = DiDiSampler(w, cfg, device="cuda", precision="fp16x2", schedule=((t_switch, "fp16x2"), (0, "fp16x3")))
+    precs = part.call_precisions(plan.time_row)
+    k0 = next(k for k, p in enumerate(precs) if p == 5)
+    assert 0 < k0 < n_calls and sum(p == 5 for p in precs) == 2
     _, part_tr = go(part)
-    assert all(torch.equal(a, b) for a, b in zip(plain_tr[: k0 + 1], part_tr[: k0 + 1])), "calls before the tail are untouched"
-    assert not torch.equal(plain_tr[-1], part_tr[-1]), "the tail's first call runs in another precision: the next input differs"
-    with pytest.raises(ValueError):
-        DiDiSampler(w, cfg, device="cuda", precision="bf16x3", tail_calls=2)
+    assert all(torch.equal(a, b) for a, b in zip(plain_tr[: k0 + 1], part_tr[: k0 + 1])), "calls before the switch are untouched"
+    if k0 + 1 < n_calls:
+        assert not torch.equal(plain_tr[k0 + 1], part_tr[k0 + 1]), "the first fp16x3 call changes the next input"
+    for bad in (dict(precision="bf16x3", schedule=((0, "fp16x3"),)), dict(precision="fp16", schedule=((5, "fp16"),)),
+                dict(precision="fp16", schedule=((5, "fp16"), (9, "fp16x2"), (0, "fp16x3")))):
+        with pytest.raises(ValueError):
+            DiDiSampler(w, cfg, device="cuda", **bad)
     # the Python loop (torch-drawn noise) follows the same schedule as the native loop
     shape = tuple(t["noise.0"].shape)
     torch.cuda.manual_seed(3)

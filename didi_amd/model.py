@@ -81,7 +81,15 @@ class DiDiSampler:
         if precision not in ("bf16", "fp16", "fp16x2", "bf16x3"):
             raise ValueError("precision must be one of bf16, fp16, fp16x2, bf16x3, fp16-sched")
         if schedule is not None:  # thresholds below 1 are fractions of T
-            schedule = tuple((int(round(t * cfg.diffusion_steps)) if 0 < t < 1 else int(t), p) for t, p in schedule)
+            resolved = []
+            for t, p in schedule:
+                frac = 0 < t < 1
+                t = int(round(t * cfg.diffusion_steps)) if frac else int(t)
+                if resolved and resolved[-1][0] == t and (frac or resolved[-1][2]):
+                    resolved.pop()  # a small T collapses fractional thresholds: the later (more precise) regime keeps the slot
+                resolved.append((t, p, frac))
+            resolved = [(t, p) for t, p, _ in resolved]
+            schedule = tuple(resolved)
             ok = precision in ("fp16", "fp16x2") and all(p in ("fp16", "fp16x2", "fp16x3") for _, p in schedule)
             ok = ok and schedule[-1][0] == 0 and all(a[0] > b[0] for a, b in zip(schedule, schedule[1:]))
             if not ok:

@@ -124,3 +124,34 @@ def test_sample_sharded_world2_gloo_empty_shard():
     """B = 1 < world: rank 1 has nothing to sample and still takes part in the gather."""
     assert _run(_sharded_worker, (1, 4, False), 2) == [(0, True, True), (1, True, True)]
     assert _run(_sharded_worker, (1, 4, True), 2) == [(0, True, True), (1, True, True)]
+
+
+def _grad_worker(rank, world, port, bucket_bytes, q):
+    from didi_amd.dist import allreduce_gradients
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shapes = [(7, 5), (3,), (64, 33), (1,), (130,)]
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = [torch.randn(*s, generator=g) for s in shapes]
+    metrics = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0]) * (rank + 1)
+    want = []
+    for s in shapes:  # the mean over ranks of what each rank drew
+        acc = torch.zeros(*s)
+        for r in range(world):
+            gr = torch.Generator().manual_seed(100 + r)
+            per = [torch.randn(*s2, generator=gr) for s2 in shapes]
+            acc += per[shapes.index(s)]
+        want.append(acc / world)
+    m = allreduce_gradients(grads, world, metrics=metrics, bucket_bytes=bucket_bytes)
+    ok = all(torch.allclose(a, b, atol=1e-6) for a, b in zip(grads, want))
+    ok = ok and torch.allclose(m, torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0]) * (sum(range(1, world + 1)) / world))
+    q.put((rank, bool(ok), True))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo_one_bucket_and_many():
+    """The training step's gradient all-reduce + the five metric scalars in the same message: one bucket, and buckets smaller
+    than a tensor (every tensor its own bucket) give the same averages on both ranks."""
+    assert _run(_grad_worker, (64 << 20,), 2) == [(0, True, True), (1, True, True)]
+    assert _run(_grad_worker, (64,), 2) == [(0, True, True), (1, True, True)]

@@ -62,7 +62,7 @@ class AttnArgs(C.Structure):
         ("K_hi", C.c_void_p), ("K_lo", C.c_void_p), ("ldk", C.c_int),
         ("V_hi", C.c_void_p), ("V_lo", C.c_void_p), ("ldv", C.c_int),
         ("O_hi", C.c_void_p), ("O_lo", C.c_void_p), ("ldo", C.c_int),
-        ("scale", C.c_float), ("pos_bias", C.c_void_p),
+        ("scale", C.c_float), ("pos_bias", C.c_void_p), ("key_count", C.c_void_p),
     ]
 
 
@@ -90,7 +90,7 @@ class ForwardArgs(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("S", C.c_int), ("C", C.c_int), ("precision", C.c_int),
         ("step", StepArgs),
-        ("kv_hi", C.c_void_p), ("kv_lo", C.c_void_p), ("ctx_mask", C.c_void_p),
+        ("kv_hi", C.c_void_p), ("kv_lo", C.c_void_p), ("ctx_mask", C.c_void_p), ("ctx_count", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("x0_f32", C.c_void_p), ("x0_hi", C.c_void_p), ("x0_lo", C.c_void_p),
         ("prof_events_host", C.POINTER(C.c_void_p)), ("prof_capacity", C.c_int), ("prof_used_host", C.POINTER(C.c_int)),
@@ -103,7 +103,7 @@ class SampleArgs(C.Structure):
         ("B", C.c_int), ("S", C.c_int), ("C", C.c_int), ("precision", C.c_int), ("euler", C.c_int), ("n_calls", C.c_int),
         ("time_row_host", i32p), ("c0_host", f32p), ("c1_host", f32p), ("c2_host", f32p),
         ("init_scale", C.c_float), ("noise", C.c_void_p), ("seed", C.c_uint64), ("base_offset", C.c_uint64),
-        ("xt_trace", C.c_void_p), ("kv_hi", C.c_void_p), ("kv_lo", C.c_void_p), ("ctx_mask", C.c_void_p),
+        ("xt_trace", C.c_void_p), ("kv_hi", C.c_void_p), ("kv_lo", C.c_void_p), ("ctx_mask", C.c_void_p), ("ctx_count", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("x_state", C.c_void_p), ("x0_f32", C.c_void_p), ("x0_hi", C.c_void_p), ("x0_lo", C.c_void_p),
         ("cls_hi", C.c_void_p), ("cls_lo", C.c_void_p), ("V", C.c_int), ("argmax_partial", C.c_void_p),
@@ -150,6 +150,7 @@ SYMBOLS = [
                                            C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("didi_first_eos", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     ("didi_attention", C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
+    ("didi_key_counts", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("didi_decoder_workspace_bytes", C.c_size_t, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int]),
     ("didi_decoder_kv_plane_bytes", C.c_size_t, [C.POINTER(Decoder), C.c_int, C.c_int]),
     ("didi_decoder_prepare_context", C.c_int, [C.POINTER(Decoder), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

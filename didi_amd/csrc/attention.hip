@@ -32,6 +32,7 @@ struct AttnParams {
     int causal;
     float scale;  // 1/sqrt(D) * log2(e): the softmax runs in base 2
     const int32_t* key_mask;
+    const int32_t* key_count;  // [B] or null: key_mask[b] is 1 for the first key_count[b] keys and 0 after (right padding)
     const float* pos_bias;  // [heads][Sq][Sk] additive score bias (T5 relative positions) or null
     const u16* Q[2]; int ldq;
     const u16* K[2]; int ldk;
@@ -86,7 +87,15 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
     float* mb = reinterpret_cast<float*>(Vs + NPL * plane);  // [CP] additive key bias: 0, NEG (masked) or -inf (padding)
 
     const int nqb = p.SP / 16;
-    const int nkt_real = (p.Sk + 15) / 16;
+    // right-padded contexts (every CommonSense batch: mean length 24 of 64): keys from key_count[b] on are masked, their softmax
+    // weight is exp2(NEG - max) = 0 exactly, so neither their K / V rows nor their 16-key tiles are touched.  One scalar load per
+    // workgroup; a count of 0 (nothing visible: the reference's uniform-attention corner) keeps the full masked path.
+    int kc = p.Sk;
+    if (p.key_count) {
+        const int c = __builtin_amdgcn_readfirstlane(p.key_count[b]);
+        if (c > 0 && c < p.Sk) kc = c;
+    }
+    const int nkt_real = (kc + 15) / 16;
 
     // Q fragments of one 16-query block: global -> registers (B-operand rows)
     bf16x8 qh0, qh1, ql0, ql1, nh0, nh1, nl0, nl1;
@@ -112,7 +121,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                               \
             const int i_ = tid + j * 256;                                                              \
             const int r_ = i_ / CH, c_ = i_ % CH;                                                      \
-            const bool ok_ = r_ < p.Sk && c_ * 8 < p.d;                                                \
+            const bool ok_ = r_ < kc && c_ * 8 < p.d;                                                  \
             _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                       \
                 kr[j][pl] = make_uint4(0, 0, 0, 0);                                                    \
                 vr[j][pl] = make_uint4(0, 0, 0, 0);                                                    \
@@ -142,7 +151,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
     DIDI_LOAD_KV(head0);
     for (int c = tid; c < CP; c += 256) {
         float f = 0.f;
-        if (c >= p.Sk) f = -INFINITY;
+        if (c >= kc) f = -INFINITY;
         else if (p.key_mask && p.key_mask[(size_t)b * p.Sk + c] == 0) f = NEG;
         mb[c] = f;
     }
@@ -309,7 +318,7 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
     if (a->B == 0) return DIDI_OK;
     AttnParams p{};
     p.B = a->B; p.heads = a->heads; p.Sq = a->Sq; p.Sk = a->Sk;
-    p.causal = a->causal; p.d = a->D; p.key_mask = a->key_mask;
+    p.causal = a->causal; p.d = a->D; p.key_mask = a->key_mask; p.key_count = a->key_mask ? a->key_count : nullptr;
     p.scale = 1.4426950408889634f * (a->scale > 0.f ? a->scale : 1.0f / sqrtf((float)a->D));  // softmax scale * log2(e)
     p.pos_bias = a->pos_bias;
     p.Q[0] = a->Q_hi; p.Q[1] = a->Q_lo; p.ldq = a->ldq;
@@ -348,6 +357,30 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
         else DIDI_ATTN(32, 1, false);
     }
 #undef DIDI_ATTN
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ key counts of right-padded masks
+// counts[b] = number of 1s of mask[b, :] when they form a prefix (1...1 0...0), else Sk (= no trimming): what didi_attention's
+// key_count takes.  One pass over the [B, Sk] mask, once per batch.
+__global__ void __launch_bounds__(256) key_counts_kernel(const int32_t* mask, int B, int Sk, int32_t* counts) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    int n = 0;
+    bool prefix = true;
+    for (int c = 0; c < Sk; ++c) {
+        const bool on = mask[(size_t)b * Sk + c] != 0;
+        if (on && n != c) prefix = false;
+        n += on;
+    }
+    counts[b] = prefix ? n : Sk;
+}
+
+extern "C" int didi_key_counts(const int32_t* mask, int B, int Sk, int32_t* counts, void* stream) {
+    DIDI_CHECK_ARG(mask && counts && B >= 0 && Sk > 0);
+    if (B == 0) return DIDI_OK;
+    key_counts_kernel<<<cdiv(B, 256), 256, 0, as_stream(stream)>>>(mask, B, Sk, counts);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

@@ -252,7 +252,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         u16* q_lo = x3 ? w.qkv_lo : nullptr;
         TRY(gemm(ly.cq, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream, &prof, w.small_ws, a->fault));
         const size_t kvoff = (size_t)l * Mc * 2 * H;
-        at.Sk = a->C; at.causal = 0; at.key_mask = a->ctx_mask;
+        at.Sk = a->C; at.causal = 0; at.key_mask = a->ctx_mask; at.key_count = a->ctx_count;
         at.Q_hi = q_hi; at.Q_lo = q_lo; at.ldq = H;
         at.K_hi = a->kv_hi + kvoff; at.K_lo = x3 ? a->kv_lo + kvoff : nullptr; at.ldk = 2 * H;
         at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;
@@ -290,7 +290,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
 
     didi_forward_args f{};
     f.B = s->B; f.S = s->S; f.C = s->C; f.precision = s->precision;
-    f.kv_hi = s->kv_hi; f.kv_lo = s->kv_lo; f.ctx_mask = s->ctx_mask;
+    f.kv_hi = s->kv_hi; f.kv_lo = s->kv_lo; f.ctx_mask = s->ctx_mask; f.ctx_count = s->ctx_count;
     f.workspace = s->workspace; f.workspace_bytes = s->workspace_bytes;
     f.x0_f32 = s->x0_f32;
     f.fault = s->fault;

@@ -368,6 +368,7 @@ class DiDiSampler:
         if self._ctx_key != key:
             ctx = context.contiguous().float()
             b["mask32"] = attention_mask.to(torch.int32).contiguous()
+            b["count32"] = ops.key_counts(b["mask32"])  # right-padded contexts: padded keys are neither loaded nor multiplied
             _lib.check(lib.didi_decoder_prepare_context(C.byref(self._dec), ctx.data_ptr(), B, Cn, self.prec, b["ws"].data_ptr(),
                                                         b["ws_bytes"], b["kv_hi"].data_ptr(), b["kv_lo"].data_ptr(),
                                                         _lib.current_stream()), "prepare_context")
@@ -393,6 +394,7 @@ class DiDiSampler:
         fa.B, fa.S, fa.C, fa.precision = B, S, context.shape[1], self.prec
         fa.step.mode, fa.step.X, fa.step.cin, fa.step.time_idx = _lib.STEP_NONE, x.data_ptr(), 1.0, tidx.data_ptr()
         fa.kv_hi, fa.kv_lo, fa.ctx_mask = b["kv_hi"].data_ptr(), b["kv_lo"].data_ptr(), b["mask32"].data_ptr()
+        fa.ctx_count = b["count32"].data_ptr()
         fa.workspace, fa.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
         fa.x0_f32 = out.data_ptr()
         fa.fault = b["fault"].data_ptr()

@@ -139,7 +139,15 @@ def gemm_ln(a_hi, a_lo, w_hi, w_lo, bias, residual_planes, gamma, beta, eps, pre
     return y_hi, y_lo, y
 
 
-def attention(q, k, v, heads, causal=False, key_mask=None, precision="bf16x3", scale=None, pos_bias=None):
+def key_counts(mask32):
+    """int32 [B, Sk] mask -> int32 [B]: visible keys per row when they form a prefix (right padding), else Sk."""
+    B, Sk = mask32.shape
+    counts = torch.empty(B, dtype=torch.int32, device=mask32.device)
+    _lib.check(lib.didi_key_counts(mask32.data_ptr(), B, Sk, counts.data_ptr(), _lib.current_stream()), "key_counts")
+    return counts
+
+
+def attention(q, k, v, heads, causal=False, key_mask=None, precision="bf16x3", scale=None, pos_bias=None, key_count=None):
     """q/k/v: (hi, lo) plane pairs shaped [B, S, heads*D] (views with a row stride are fine).
     ``scale``: softmax scale (default 1/sqrt(D)); ``pos_bias``: fp32 [heads, Sq, Sk] added to the scaled scores (T5)."""
     B, Sq, HD = q[0].shape
@@ -147,6 +155,7 @@ def attention(q, k, v, heads, causal=False, key_mask=None, precision="bf16x3", s
     a = _lib.AttnArgs()
     a.B, a.heads, a.Sq, a.Sk, a.D = B, heads, Sq, Sk, HD // heads
     a.precision, a.causal, a.key_mask = _prec(precision), int(causal), _lib.ptr(key_mask)
+    a.key_count = _lib.ptr(key_count)
     a.Q_hi, a.Q_lo, a.ldq = q[0].data_ptr(), _lib.ptr(q[1]), q[0].stride(1)
     a.K_hi, a.K_lo, a.ldk = k[0].data_ptr(), _lib.ptr(k[1]), k[0].stride(1)
     a.V_hi, a.V_lo, a.ldv = v[0].data_ptr(), _lib.ptr(v[1]), v[0].stride(1)

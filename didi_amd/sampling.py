@@ -124,6 +124,7 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
         a.noise, a.seed, a.base_offset = _lib.ptr(noise_t), seed, base_offset
         a.xt_trace = _lib.ptr(xt_trace)
         a.kv_hi, a.kv_lo, a.ctx_mask = b["kv_hi"].data_ptr(), b["kv_lo"].data_ptr(), b["mask32"].data_ptr()
+        a.ctx_count = b["count32"].data_ptr()
         a.workspace, a.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
         a.x_state, a.x0_f32 = b["x_state"].data_ptr(), b["x0"].data_ptr()
         a.x0_hi, a.x0_lo = b["x0_hi"].data_ptr(), b["x0_lo"].data_ptr()
@@ -187,6 +188,7 @@ def _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp=False):
             xin = torch.empty((B, S, H), dtype=torch.float32, device=dev)
             st.xin_out = xin.data_ptr()
         fa.kv_hi, fa.kv_lo, fa.ctx_mask = b["kv_hi"].data_ptr(), b["kv_lo"].data_ptr(), b["mask32"].data_ptr()
+        fa.ctx_count = b["count32"].data_ptr()
         fa.workspace, fa.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
         fa.x0_f32 = x0.data_ptr()
         fa.fault = b["fault"].data_ptr()

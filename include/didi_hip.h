@@ -315,8 +315,14 @@ typedef struct didi_attn_args {
     float scale;           /* softmax scale; 0 = 1/sqrt(D) (BERT, Blenderbot).  T5 passes 1: it folds the scale into its init */
     const float* pos_bias; /* [heads][Sq][Sk] fp32 added to the scaled scores before the mask, or NULL: T5's relative
                               position bias (HF:models/t5/modeling_t5.py T5Attention.compute_bias) */
+    const int32_t* key_count; /* optional, with key_mask: int32 [B] from didi_key_counts -- key_mask[b] is 1 for exactly the
+                              first key_count[b] keys (right padding, commonsense_dataset.py:27-32).  The kernel then neither
+                              loads nor multiplies the padded keys (their softmax weight is exactly 0): same result, less
+                              traffic.  NULL, or a count of 0 or Sk: the full masked path. */
 } didi_attn_args;
 int didi_attention(const didi_attn_args* a, void* stream);
+/* counts[b] = number of visible keys of mask[b, :] (int32 [B, Sk]) if they form a prefix, else Sk (no trimming). */
+int didi_key_counts(const int32_t* mask, int B, int Sk, int32_t* counts, void* stream);
 
 /* ---------------------------------------------------------------- decoder engine */
 
@@ -382,6 +388,7 @@ typedef struct didi_forward_args {
     didi_step_args step;
     const uint16_t *kv_hi, *kv_lo; /* from didi_decoder_prepare_context */
     const int32_t* ctx_mask;       /* [B, C] int32 */
+    const int32_t* ctx_count;      /* [B] int32 from didi_key_counts(ctx_mask) or NULL (see didi_attn_args.key_count) */
     void* workspace;
     size_t workspace_bytes;
     float* x0_f32;
@@ -423,6 +430,7 @@ typedef struct didi_sample_args {
     float* xt_trace;
     const uint16_t *kv_hi, *kv_lo;
     const int32_t* ctx_mask;
+    const int32_t* ctx_count; /* as didi_forward_args.ctx_count */
     void* workspace;
     size_t workspace_bytes;
     float* x_state;

@@ -515,6 +515,25 @@ def test_attention(ops, B, heads, Sq, Sk, d, causal, masked, precision):
         got, tol = o_hi.float(), (1.2e-2 if precision == "bf16" else 1.5e-3)  # P and O are additionally rounded to 16 bits
     assert rel_l2(got, want) <= tol, rel_l2(got, want)
     assert torch.isfinite(got).all()
+    if masked:  # right-padded masks: with the per-dialog key counts the padded keys are skipped -- same bits out
+        counts = ops.key_counts(key_mask.cuda())
+        assert counts.cpu().tolist() == lens.tolist()
+        c_hi, c_lo = ops.attention(qp, kp, vp, heads, causal=causal, key_mask=key_mask.cuda(), precision=precision, key_count=counts)
+        assert torch.equal(c_hi, o_hi) and (o_lo is None or torch.equal(c_lo, o_lo))
+
+
+def test_key_counts_only_trim_prefix_masks(ops):
+    mask = torch.tensor([[1, 1, 1, 0, 0, 0], [1, 0, 1, 0, 0, 0], [0, 0, 0, 0, 0, 0], [1, 1, 1, 1, 1, 1], [0, 1, 1, 1, 1, 1]], dtype=torch.int32)
+    assert ops.key_counts(mask.cuda()).cpu().tolist() == [3, 6, 0, 6, 6]  # holes / left padding: no trimming (count = Sk)
+    # a count of 0 (nothing visible) keeps the reference's uniform-attention corner: same output as without counts
+    B, S, HD, heads = 5, 6, 64, 2
+    qkv = rnd(B, S, 3 * HD, seed=3)
+    hi, lo = ops.split(qkv.cuda())
+    v3 = lambda t, i: t[:, :, i * HD:(i + 1) * HD]  # noqa: E731
+    q, k, v = ((v3(hi, i), v3(lo, i)) for i in range(3))
+    a_hi, a_lo = ops.attention(q, k, v, heads, key_mask=mask.cuda(), precision="bf16x3")
+    b_hi, b_lo = ops.attention(q, k, v, heads, key_mask=mask.cuda(), precision="bf16x3", key_count=ops.key_counts(mask.cuda()))
+    assert torch.equal(a_hi, b_hi) and torch.equal(a_lo, b_lo)
 
 
 @pytest.mark.parametrize("B,heads,S,d", [(2, 4, 40, 16), (3, 4, 23, 32), (1, 8, 96, 64)])

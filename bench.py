@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", default="fp16-sched", choices=["bf16", "fp16", "fp16x2", "fp16-sched", "fp16x3", "bf16x3"],
                     help="fp16-sched (default): fp16 planes with the precision schedule of didi_amd.model.DEFAULT_SCHEDULE (one MFMA product "
-                         "for t > 0.4 T, the weights' remainder for t > 0.064 T, all three products for the last steps): the cheapest "
+                         "for t > 0.35 T, the weights' remainder for t > 0.064 T, all three products for the last steps): the cheapest "
                          "configuration that holds ids >= 99.9 %% and x_t <= 1e-3 over the 2000-call loop at THIS model size; fp16 / fp16x2: "
                          "one / two products throughout (miss the bars at 2000 calls); fp16x3 / bf16x3: fp32-class, three products")
     ap.add_argument("--mode", default="ddpm", choices=["ddpm", "euler"])
@@ -307,7 +307,7 @@ def main():
                 "fp16-sched": ("fp16 operand planes where BASELINE configs[1] says bf16: 16-bit MFMA operands with fp32 accumulation either way; the "
                                "parity bar (ids >= 99.9 %, every x_t <= 1e-3 against the fp32 reference) decides what is multiplied: one-product "
                                "bf16 / fp16 miss it at this model size (weight rounding adds up coherently over the loop), so calls run one "
-                               "product while x_t is mostly fresh noise, add the weights' remainder plane below t = 0.4 T and multiply all three "
+                               "product while x_t is mostly fresh noise, add the weights' remainder plane below t = 0.35 T and multiply all three "
                                "products for the last 0.064 T steps: 0 of 1024 ids differ, max x_t rel-L2 5.7e-4 over 2000 calls "
                                "(profiles/r02_parity_f1_ddpm.log, tests/test_gpu_fullsize.py)"),
                 "fp16x2": "fp16 planes, A_hi*(W_hi+W_lo) in every call: holds the bars over 201 calls (step_freq 10), misses them over 2000",

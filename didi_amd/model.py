@@ -24,9 +24,9 @@ from .schedule import configure_schedule
 
 
 # Default precision schedule of "fp16-sched", as fractions of the number of diffusion steps T (measured at
-# T = 2000, sqrt schedule: t > 800 / t > 128 / the rest): one product while the input is mostly fresh noise, the weights'
+# T = 2000, sqrt schedule: t > 700 / t > 128 / the rest): one product while the input is mostly fresh noise, the weights'
 # remainder once x_t starts to carry the previous estimate, all three products for the last steps.
-DEFAULT_SCHEDULE = ((0.4, "fp16"), (0.064, "fp16x2"), (0, "fp16x3"))
+DEFAULT_SCHEDULE = ((0.35, "fp16"), (0.064, "fp16x2"), (0, "fp16x3"))
 
 
 class _Planes:

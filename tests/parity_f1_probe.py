@@ -65,10 +65,7 @@ def main():
         sched((0, "fp16x3")),
         ("fp16-sched (default) " + str(DEFAULT_SCHEDULE), dict(precision="fp16-sched")),
         sched((1000, "fp16"), (128, "fp16x2"), (0, "fp16x3")),
-        sched((400, "fp16"), (0, "fp16x3")),
         sched((600, "fp16"), (0, "fp16x3")),
-        sched((200, "fp16x2"), (0, "fp16x3")),
-        sched((64, "fp16x2"), (0, "fp16x3")),
         ("fp16x2", dict(precision="fp16x2")),
     ]
     if len(sys.argv) > 4:

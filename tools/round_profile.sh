@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round artifacts on the 1-GPU box: default bench line, kernel-trace summary of the same command, HBM-traffic PMC passes per
+# precision regime.  usage: bash tools/round_profile.sh <tag>   (outputs under gpurun_out/<tag>_*)
+set -e
+TAG=${1:-r02}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out
+timeout -k 10 400 python3 bench.py > $O/${TAG}_bench_default.log 2> $O/${TAG}_bench_default.err
+tail -c 600 $O/${TAG}_bench_default.log; echo
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o t -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/${TAG}_rocprof_bench_stdout.log 2>&1
+cp $(find $O/${TAG}_trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats.csv
+python3 tools/trace_shapes.py $(find $O/${TAG}_trace -name "*kernel_trace.csv" | head -1) | tee $O/${TAG}_kernel_shapes.txt
+rm -rf $O/${TAG}_trace
+for P in fp16 fp16x2 fp16x3; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout -s KILL 120 rocprofv3 --pmc $C --output-format csv -d $O/${TAG}_pmc_${P}_${C} -o p -- python3 bench.py --diffusion-steps 3 --steps 1 --warmup 0 --no-cpu-baseline --precision $P > /dev/null 2>&1
+  done
+  python3 tools/pmc_traffic.py $(find $O/${TAG}_pmc_${P}_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/${TAG}_pmc_${P}_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/gemm_traffic_${P}.json
+  rm -rf $O/${TAG}_pmc_${P}_FETCH_SIZE $O/${TAG}_pmc_${P}_WRITE_SIZE
+done

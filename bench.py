@@ -266,11 +266,15 @@ def main():
         w_launch += n_reg * len(dur)
     if per_regime:
         achieved = w_flop / w_time / 1e12
+        # HBM (fabric-side) bytes per GEMM launch: PMC passes are separate runs per precision (profiles/README.md); a schedule's
+        # figure is the average over its regimes weighted by their launch counts
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", f"gemm_traffic_{args.precision}.json")
-        if os.path.exists(tpath) and args.batch == 256 and args.seq == 64:  # PMC passes are a separate run (profiles/README.md)
-            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
-            traffic_src = os.path.relpath(tpath, ROOT)
+        if args.batch == 256 and args.seq == 64:
+            paths = {name: os.path.join(ROOT, "profiles", f"gemm_traffic_{name}.json") for name in per_regime}
+            if all(os.path.exists(q) for q in paths.values()):
+                tot = sum(per_regime[name]["calls"] for name in per_regime)
+                traffic = round(sum(per_regime[name]["calls"] * json.load(open(q))["hbm_bytes_per_launch"] for name, q in paths.items()) / tot)
+                traffic_src = [os.path.relpath(q, ROOT) for q in paths.values()]
         roofline = {
             "bound": "mfma", "kernel": ("gemm_pp_kernel<NPASS, F16, LN, false> (256x192 tile, staggered wave groups; NPASS = MFMA products per "
                                          "algorithmic product: 1 fp16, 2 fp16x2, 3 fp16x3/bf16x3; LN = true on the three output projections per "

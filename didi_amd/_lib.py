@@ -168,6 +168,22 @@ SYMBOLS = [
     ("didi_colsum_bytes", C.c_size_t, [C.c_int, C.c_int]),
     ("didi_colsum", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("didi_transpose_split", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    ("didi_act_backward", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    ("didi_axpby", C.c_int, [C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("didi_ce_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    ("didi_act_forward", C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    ("didi_embedding_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("didi_attention_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    ("didi_adamw_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    ("didi_sumsq_accumulate", C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    ("didi_train_embed_sum", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p]),
+    ("didi_seq_sum", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("didi_train_target_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("didi_event_create", C.c_int, [C.POINTER(C.c_void_p)]),
     ("didi_event_elapsed_ms", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     ("didi_event_destroy", C.c_int, [C.c_void_p]),

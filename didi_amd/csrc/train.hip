@@ -4,6 +4,7 @@
 // dA = dC W  is  didi_gemm(A' = dC [M,N], W' = W^T [K,N]);  dW = dC^T A  is  didi_gemm(A' = dC^T [N,M], W' = A^T [K,M])).
 // All HBM-bound, one pass each; layouts as elementwise.hip (a wave owns a row, lane l holds 16-byte chunks l + 64 j).
 #include <algorithm>
+#include <mutex>
 
 #include "common.hpp"
 #include "philox.hpp"
@@ -266,6 +267,361 @@ extern "C" int didi_transpose_split(const float* src, int R, int C, int ldo, uin
     DIDI_CHECK_ARG(src && hi && R > 0 && C > 0 && ldo >= R);
     DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
     transpose_split_kernel<<<dim3(cdiv(C, 64), cdiv(ldo, 64)), 256, 0, as_stream(stream)>>>(src, R, C, ldo, hi, lo, plane_format == DIDI_FMT_FP16);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ elementwise backward pieces
+// GELU (exact erf form, hidden_act="gelu"): du = df * (Phi(u) + u phi(u));  tanh: dz = dy * (1 - y^2) from the OUTPUT y.
+__global__ void __launch_bounds__(256) gelu_backward_kernel(const float* df, const float* u, size_t n4, float* du) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 g = reinterpret_cast<const float4*>(df)[i], x = reinterpret_cast<const float4*>(u)[i];
+    auto d = [](float v) { return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v); };
+    reinterpret_cast<float4*>(du)[i] = make_float4(g.x * d(x.x), g.y * d(x.y), g.z * d(x.z), g.w * d(x.w));
+}
+__global__ void __launch_bounds__(256) tanh_backward_kernel(const float* dy, const float* y, size_t n4, float* dz) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 g = reinterpret_cast<const float4*>(dy)[i], t = reinterpret_cast<const float4*>(y)[i];
+    reinterpret_cast<float4*>(dz)[i] = make_float4(g.x * (1.f - t.x * t.x), g.y * (1.f - t.y * t.y), g.z * (1.f - t.z * t.z), g.w * (1.f - t.w * t.w));
+}
+// y = act(x) as fp32 + split planes (the training forward keeps the pre-activation, so the activation is its own pass there)
+template <bool F16>
+__global__ void __launch_bounds__(256) act_forward_kernel(int act, const float* x, size_t n4, float* y, uint16_t* hi, uint16_t* lo) {
+    if (F16) f16_saturate_mode();
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 u = reinterpret_cast<const float4*>(x)[i];
+    auto f = [act](float v) { return act == DIDI_ACT_GELU ? 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)) : tanhf(v); };
+    const float r[4] = {f(u.x), f(u.y), f(u.z), f(u.w)};
+    if (y) reinterpret_cast<float4*>(y)[i] = make_float4(r[0], r[1], r[2], r[3]);
+    if (hi) {
+        uint2 h, l;
+        split4(r, h, l, F16);
+        reinterpret_cast<uint2*>(hi)[i] = h;
+        if (lo) reinterpret_cast<uint2*>(lo)[i] = l;
+    }
+}
+extern "C" int didi_act_forward(int act, const float* x, size_t n, float* y, void* hi, void* lo, int plane_format, void* stream) {
+    DIDI_CHECK_ARG(x && (y || hi) && n % 4 == 0 && (act == DIDI_ACT_GELU || act == DIDI_ACT_TANH));
+    DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
+    if (n == 0) return DIDI_OK;
+    const unsigned grid = (unsigned)cdiv((long)(n / 4), 256);
+    if (plane_format == DIDI_FMT_FP16)
+        act_forward_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(act, x, n / 4, y, (uint16_t*)hi, (uint16_t*)lo);
+    else
+        act_forward_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(act, x, n / 4, y, (uint16_t*)hi, (uint16_t*)lo);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+extern "C" int didi_act_backward(int act, const float* dy, const float* saved, size_t n, float* dx, void* stream) {
+    DIDI_CHECK_ARG(dy && saved && dx && n % 4 == 0 && (act == DIDI_ACT_GELU || act == DIDI_ACT_TANH));
+    if (n == 0) return DIDI_OK;
+    const unsigned grid = (unsigned)cdiv((long)(n / 4), 256);
+    if (act == DIDI_ACT_GELU) gelu_backward_kernel<<<grid, 256, 0, as_stream(stream)>>>(dy, saved, n / 4, dx);
+    else tanh_backward_kernel<<<grid, 256, 0, as_stream(stream)>>>(dy, saved, n / 4, dx);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// y[i] = a x[i] + b y[i]: gradient accumulation where two paths meet (residual connections, x_0's several consumers)
+__global__ void __launch_bounds__(256) axpby_kernel(float a, const float* x, float b, float* y, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 u = reinterpret_cast<const float4*>(x)[i];
+    float4 v = reinterpret_cast<float4*>(y)[i];
+    v = make_float4(a * u.x + b * v.x, a * u.y + b * v.y, a * u.z + b * v.z, a * u.w + b * v.w);
+    reinterpret_cast<float4*>(y)[i] = v;
+}
+extern "C" int didi_axpby(float a, const float* x, float b, float* y, size_t n, void* stream) {
+    DIDI_CHECK_ARG(x && y && n % 4 == 0);
+    if (n == 0) return DIDI_OK;
+    axpby_kernel<<<(unsigned)cdiv((long)(n / 4), 256), 256, 0, as_stream(stream)>>>(a, x, b, y, n / 4);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ cross-entropy backward on materialised logits
+// calculate_batch_ce (src/metrics.py:91-93) = mean over non-pad tokens of -log softmax(logits)[target]:
+// dlogits[m, :] = w_m (softmax(logits[m, :]) - onehot(target_m)), w_m = scale for kept tokens, 0 for padding.  In place.
+// One 256-thread workgroup per row; V up to the vocabulary (50 000: 196 values per thread in three passes over L2-resident data).
+__global__ void __launch_bounds__(256) ce_backward_kernel(float* logits, const int64_t* targets, const int64_t* mask, int V, float scale,
+                                                          float* nll) {
+    __shared__ float red[4];
+    float* row = logits + (size_t)blockIdx.x * V;
+    const bool keep = mask[blockIdx.x] != 0;
+    float mx = -INFINITY;
+    if (keep)
+        for (int n = threadIdx.x; n < V; n += 256) mx = fmaxf(mx, row[n]);
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    if (keep)
+        for (int n = threadIdx.x; n < V; n += 256) s += __expf(row[n] - mx);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    const float inv = keep ? scale / s : 0.f;
+    const int64_t tg = targets[blockIdx.x];
+    if (nll && threadIdx.x == 0) nll[blockIdx.x] = keep ? __logf(s) + mx - row[tg] : 0.f;
+    __syncthreads();  // the target's logit is read before any lane overwrites it
+    for (int n = threadIdx.x; n < V; n += 256) {
+        float g = keep ? __expf(row[n] - mx) * inv : 0.f;
+        if (keep && n == tg) g -= scale;
+        row[n] = g;
+    }
+}
+extern "C" int didi_ce_backward(float* logits, const int64_t* targets, const int64_t* mask, int M, int V, float scale, float* nll,
+                                void* stream) {
+    DIDI_CHECK_ARG(logits && targets && mask && M >= 0 && V > 0);
+    if (M == 0) return DIDI_OK;
+    ce_backward_kernel<<<M, 256, 0, as_stream(stream)>>>(logits, targets, mask, V, scale, nll);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ embedding gradients: table_grad[ids[m], :] += scale * dy[m, :]
+// nn.Embedding backward (float atomics: rows repeat within a batch); rows equal to `skip_id` (padding_idx, model.py:104) get none.
+__global__ void __launch_bounds__(256) embedding_backward_kernel(const int64_t* ids, const float* dy, int M, int H, float scale,
+                                                                 int64_t skip_id, float* grad) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int64_t id = ids[m];
+    if (id == skip_id) return;
+    for (int c = lane; c < H; c += 64) atomicAdd(grad + (size_t)id * H + c, scale * dy[(size_t)m * H + c]);
+}
+extern "C" int didi_embedding_backward(const int64_t* ids, const float* dy, int M, int H, float scale, int64_t skip_id, float* grad,
+                                       void* stream) {
+    DIDI_CHECK_ARG(ids && dy && grad && M >= 0 && H > 0);
+    if (M == 0) return DIDI_OK;
+    embedding_backward_kernel<<<cdiv(M, 4), 256, 0, as_stream(stream)>>>(ids, dy, M, H, scale, skip_id, grad);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ attention backward (fp32, one workgroup per (dialog, head))
+// O = softmax(Q K^T s + mask) V.  With P the probabilities and D_i = sum_j P_ij dP_ij (= dO_i . O_i):
+//   dV = P^T dO,  dP = dO V^T,  dS = P o (dP - D) s,  dQ = dS K,  dK = dS^T Q.
+// Everything of one head lives in LDS as fp32 (Sq, Sk <= 96, D <= 64: 4 x 24 KiB operands + 36 KiB of P): recomputes P from
+// Q and K instead of saving it.  Plain fp32 FMA loops -- a first, correctness-level version (the sampler never runs it).
+__global__ void __launch_bounds__(256) attention_backward_kernel(const float* Q, const float* K, const float* V, const float* dO,
+                                                                 const int32_t* key_mask, int heads, int Sq, int Sk, int D, int ldq,
+                                                                 int ldk, int ldv, int ldo, int causal, float scale, float* dQ,
+                                                                 float* dK, float* dV) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x;
+    float* q = sm;                 // [Sq][D]
+    float* k = q + Sq * D;         // [Sk][D]
+    float* v = k + Sk * D;         // [Sk][D]
+    float* g = v + Sk * D;         // dO [Sq][D]
+    float* P = g + Sq * D;         // [Sq][Sk] probabilities, then dS
+    float* Dr = P + Sq * Sk;       // [Sq]
+    for (int i = tid; i < Sq * D; i += 256) {
+        const int r = i / D, c = i % D;
+        q[i] = Q[((size_t)b * Sq + r) * ldq + h * D + c];
+        g[i] = dO[((size_t)b * Sq + r) * ldo + h * D + c];
+    }
+    for (int i = tid; i < Sk * D; i += 256) {
+        const int r = i / D, c = i % D;
+        k[i] = K[((size_t)b * Sk + r) * ldk + h * D + c];
+        v[i] = V[((size_t)b * Sk + r) * ldv + h * D + c];
+    }
+    __syncthreads();
+    constexpr float NEG = -3.4028234663852886e38f;
+    for (int i = tid; i < Sq * Sk; i += 256) {
+        const int r = i / Sk, c = i % Sk;
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s += q[r * D + d] * k[c * D + d];
+        s *= scale;
+        if ((key_mask && key_mask[(size_t)b * Sk + c] == 0) || (causal && c > r)) s = fminf(s + NEG, NEG);
+        P[i] = s;
+    }
+    __syncthreads();
+    for (int r = tid; r < Sq; r += 256) {  // row softmax
+        float mx = -INFINITY, sum = 0.f;
+        for (int c = 0; c < Sk; ++c) mx = fmaxf(mx, P[r * Sk + c]);
+        for (int c = 0; c < Sk; ++c) { const float e = __expf(P[r * Sk + c] - mx); P[r * Sk + c] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int c = 0; c < Sk; ++c) P[r * Sk + c] *= inv;
+    }
+    __syncthreads();
+    for (int i = tid; i < Sk * D; i += 256) {  // dV = P^T dO
+        const int c = i / D, d = i % D;
+        float a = 0.f;
+        for (int r = 0; r < Sq; ++r) a += P[r * Sk + c] * g[r * D + d];
+        dV[((size_t)b * Sk + c) * ldv + h * D + d] = a;
+    }
+    for (int r = tid; r < Sq; r += 256) Dr[r] = 0.f;
+    __syncthreads();
+    // dP_ij = dO_i . V_j ; D_i = sum_j P_ij dP_ij
+    for (int i = tid; i < Sq * Sk; i += 256) {
+        const int r = i / Sk, c = i % Sk;
+        float a = 0.f;
+        for (int d = 0; d < D; ++d) a += g[r * D + d] * v[c * D + d];
+        atomicAdd(&Dr[r], P[i] * a);
+    }
+    __syncthreads();
+    for (int i = tid; i < Sq * Sk; i += 256) {
+        const int r = i / Sk, c = i % Sk;
+        float a = 0.f;
+        for (int d = 0; d < D; ++d) a += g[r * D + d] * v[c * D + d];
+        P[i] = P[i] * (a - Dr[r]) * scale;  // dS
+    }
+    __syncthreads();
+    for (int i = tid; i < Sq * D; i += 256) {  // dQ = dS K
+        const int r = i / D, d = i % D;
+        float a = 0.f;
+        for (int c = 0; c < Sk; ++c) a += P[r * Sk + c] * k[c * D + d];
+        dQ[((size_t)b * Sq + r) * ldq + h * D + d] = a;
+    }
+    for (int i = tid; i < Sk * D; i += 256) {  // dK = dS^T Q
+        const int c = i / D, d = i % D;
+        float a = 0.f;
+        for (int r = 0; r < Sq; ++r) a += P[r * Sk + c] * q[r * D + d];
+        dK[((size_t)b * Sk + c) * ldk + h * D + d] = a;
+    }
+}
+
+extern "C" int didi_attention_backward(const float* Q, const float* K, const float* V, const float* dO, const int32_t* key_mask, int B,
+                                       int heads, int Sq, int Sk, int D, int ldq, int ldk, int ldv, int ldo, int causal, float scale,
+                                       float* dQ, float* dK, float* dV, void* stream) {
+    DIDI_CHECK_ARG(Q && K && V && dO && dQ && dK && dV && B >= 0 && heads > 0 && Sq > 0 && Sk > 0 && D > 0);
+    if (Sq > 96 || Sk > 96 || D > 64) return DIDI_ERR_UNSUPPORTED;
+    if (causal && Sq != Sk) return DIDI_ERR_BAD_ARG;
+    if (B == 0) return DIDI_OK;
+    const size_t lds = sizeof(float) * ((size_t)2 * Sq * D + 2 * Sk * D + (size_t)Sq * Sk + Sq);
+    static std::mutex mu;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
+            return DIDI_ERR_LAUNCH;
+    }
+    attention_backward_kernel<<<dim3(heads, B), 256, lds, as_stream(stream)>>>(Q, K, V, dO, key_mask, heads, Sq, Sk, D, ldq, ldk, ldv, ldo, causal,
+                                                                             scale > 0.f ? scale : 1.0f / sqrtf((float)D), dQ, dK, dV);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ AdamW (torch.optim.AdamW semantics, model.py:136-158)
+// p -= lr wd p ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr (m / bc1) / (sqrt(v / bc2) + eps), with g pre-scaled by
+// `gscale` (the gradient-clipping coefficient, configs/train.yaml:45).  bc1 = 1 - b1^t, bc2 = 1 - b2^t from the caller.
+__global__ void __launch_bounds__(256) adamw_kernel(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2, const float* gscale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gs = gscale ? *gscale : 1.0f;
+    const float gi = g[i] * gs;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    pi -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+}
+extern "C" int didi_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int step, const float* gscale, void* stream) {
+    DIDI_CHECK_ARG(p && g && m && v && step >= 1);
+    if (n == 0) return DIDI_OK;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    adamw_kernel<<<(unsigned)cdiv((long)n, 256), 256, 0, as_stream(stream)>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, gscale);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// sum of squares of x (for the global gradient norm): out[0] += sum x^2 (float atomic per block; out zeroed by the caller)
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* x, size_t n, float* out) {
+    __shared__ float red[4];
+    float a = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a += x[i] * x[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+extern "C" int didi_sumsq_accumulate(const float* x, size_t n, float* out, void* stream) {
+    DIDI_CHECK_ARG(x && out);
+    if (n == 0) return DIDI_OK;
+    const unsigned grid = (unsigned)std::min<long>(1024, cdiv((long)n, 256));
+    sumsq_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, n, out);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ decoder input of the training forward, kept in fp32
+// x_in[b, s, :] = x_t[b, s, :] + time_embeds[t_b, :] + pos[s, :] + tok0   (model.py:190-191 + BertEmbeddings with inputs_embeds,
+// HF:models/bert/modeling_bert.py:95-115).  The sampler fuses this into its LayerNorm kernel; training keeps the LayerNorm INPUT
+// because the backward needs it.
+__global__ void __launch_bounds__(256) train_embed_sum_kernel(const float* xt, const float* te, const int64_t* t, const float* pos,
+                                                              const float* tok0, int S, int H4, size_t n4, float* out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)(i % H4);
+    const size_t row = i / H4;
+    const int s = (int)(row % S);
+    const int64_t tb = t[row / S];
+    const float4 a = reinterpret_cast<const float4*>(xt)[i], b = reinterpret_cast<const float4*>(te)[(size_t)tb * H4 + c],
+                 p = reinterpret_cast<const float4*>(pos)[(size_t)s * H4 + c], k = reinterpret_cast<const float4*>(tok0)[c];
+    reinterpret_cast<float4*>(out)[i] = make_float4(a.x + b.x + p.x + k.x, a.y + b.y + p.y + k.y, a.z + b.z + p.z + k.z, a.w + b.w + p.w + k.w);
+}
+extern "C" int didi_train_embed_sum(const float* x_t, const float* time_embeds, const int64_t* t, const float* pos_emb, const float* tok0,
+                                    int B, int S, int H, float* out, void* stream) {
+    DIDI_CHECK_ARG(x_t && time_embeds && t && pos_emb && tok0 && out && B >= 0 && S > 0 && H > 0 && H % 4 == 0);
+    const size_t n4 = (size_t)B * S * (H / 4);
+    if (n4 == 0) return DIDI_OK;
+    train_embed_sum_kernel<<<(unsigned)cdiv((long)n4, 256), 256, 0, as_stream(stream)>>>(x_t, time_embeds, t, pos_emb, tok0, S, H / 4, n4, out);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// out[b, c] = sum_s x[b, s, c]: the per-dialog sums that scatter into the time-embedding rows
+__global__ void __launch_bounds__(256) seq_sum_kernel(const float* x, int S, int H, float* out) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += x[((size_t)b * S + s) * H + c];
+        out[(size_t)b * H + c] = a;
+    }
+}
+extern "C" int didi_seq_sum(const float* x, int B, int S, int H, float* out, void* stream) {
+    DIDI_CHECK_ARG(x && out && B >= 0 && S > 0 && H > 0);
+    if (B == 0) return DIDI_OK;
+    seq_sum_kernel<<<B, 256, 0, as_stream(stream)>>>(x, S, H, out);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ gradient arriving at the target embeddings (model.py:202-235)
+// emb feeds the loss four ways: the mse's t == 1 branch directly, and through x_0 = emb + std_0 n0 the mse's other branch,
+// t_T = mean(x_0^2 m) / (sigma_T^2 + 1), x_t = (x_0 + s n1) c (weight c_b of the decoder-input gradient) and, without the anchor
+// loss, the cross-entropy on classifier(x_0) (`extra`).  One pass:
+//   out = m (-w_emb (x0hat - emb) - w_x0 (x0hat - x0) + w_T x0) + c_b dxt + extra
+__global__ void __launch_bounds__(256) train_target_backward_kernel(const float* x0hat, const float* emb, const float* x0, const int64_t* mask,
+                                                                    float w_emb, float w_x0, float w_T, const float* c_b, const float* dxt,
+                                                                    const float* extra, int S, int H4, size_t n4, float* out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const size_t row = i / H4;
+    const float m = mask[row] != 0 ? 1.f : 0.f, cb = c_b[row / S];
+    const float4 h = reinterpret_cast<const float4*>(x0hat)[i], e = reinterpret_cast<const float4*>(emb)[i],
+                 z = reinterpret_cast<const float4*>(x0)[i], g = reinterpret_cast<const float4*>(dxt)[i];
+    float4 x = extra ? reinterpret_cast<const float4*>(extra)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto f = [&](float hh, float ee, float zz, float gg, float xx) { return m * (-w_emb * (hh - ee) - w_x0 * (hh - zz) + w_T * zz) + cb * gg + xx; };
+    reinterpret_cast<float4*>(out)[i] = make_float4(f(h.x, e.x, z.x, g.x, x.x), f(h.y, e.y, z.y, g.y, x.y), f(h.z, e.z, z.z, g.z, x.z), f(h.w, e.w, z.w, g.w, x.w));
+}
+extern "C" int didi_train_target_backward(const float* x0hat, const float* emb, const float* x0, const int64_t* mask, float w_emb, float w_x0,
+                                          float w_T, const float* c_b, const float* dxt, const float* extra, int B, int S, int H, float* out,
+                                          void* stream) {
+    DIDI_CHECK_ARG(x0hat && emb && x0 && mask && c_b && dxt && out && B >= 0 && S > 0 && H > 0 && H % 4 == 0);
+    const size_t n4 = (size_t)B * S * (H / 4);
+    if (n4 == 0) return DIDI_OK;
+    train_target_backward_kernel<<<(unsigned)cdiv((long)n4, 256), 256, 0, as_stream(stream)>>>(x0hat, emb, x0, mask, w_emb, w_x0, w_T, c_b, dxt, extra, S,
+                                                                                           H / 4, n4, out);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

@@ -231,6 +231,17 @@ class DiDiSampler:
 
     def _encode_context(self, input_ids, attention_mask):
         """``DiDi._encode_context`` (model.py:165-170): encoder last_hidden_state (+ adapter) -> fp32 [B, C, H]."""
+        cfg, e, P = self.cfg, self._enc, "bf16x3"
+        B, Cn = input_ids.shape
+        c_hi, c_lo, ctx = self._encode_raw(input_ids, attention_mask)
+        if cfg.has_adapter:
+            t_hi, t_lo, _ = e["ad0"](c_hi, c_lo, P, act="tanh")
+            _, _, ctx = e["ad2"](t_hi, t_lo, P, out_f32=True, out_planes=False)
+        return ctx.view(B, Cn, cfg.dec_dim)
+
+    def _encode_raw(self, input_ids, attention_mask):
+        """The encoder's last_hidden_state before the adapter -> (hi, lo bf16 planes, fp32), each [B*C, enc_dim].  The training
+        step (didi_amd/trainer.py) starts its trainable graph here: the encoder is frozen (configs/train.yaml:19)."""
         cfg, e, P = self.cfg, self._enc, "bf16x3"  # cold path (1 of ~2000 calls): always fp32-class
         B, Cn = input_ids.shape
         E, A = cfg.enc_dim, cfg.enc_heads
@@ -295,10 +306,7 @@ class DiDiSampler:
                 _, _, t = ly["fc2"](f_hi, f_lo, P, residual_planes=(h_hi, h_lo), out_f32=True, out_planes=False)
                 h_hi, h_lo, ctx = ops.layernorm(t, *ly["ln2"], 1e-12, f32=True)
             c_hi, c_lo = h_hi, h_lo
-        if cfg.has_adapter:
-            t_hi, t_lo, _ = e["ad0"](c_hi, c_lo, P, act="tanh")
-            _, _, ctx = e["ad2"](t_hi, t_lo, P, out_f32=True, out_planes=False)
-        return ctx.view(B, Cn, cfg.dec_dim)
+        return c_hi, c_lo, ctx
 
     def _t5_position_bias(self, c):
         """[heads, C, C] fp32 relative position bias of T5Attention.compute_bias (HF:models/t5/modeling_t5.py:217-279),

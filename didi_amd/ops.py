@@ -311,8 +311,8 @@ def transpose_split(x, dtype=torch.bfloat16):
     return hi, lo
 
 
-def linear_backward(dC, A, W, precision="bf16x3"):
-    """Backward of C = A W^T + b (nn.Linear): dC [M,N], A [M,K], W [N,K] fp32 -> (dA [M,K], dW [N,K], db [N]).
+def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True):
+    """Backward of C = A W^T + b (nn.Linear): dC [M,N], A [M,K], W [N,K] fp32 -> (dA [M,K], dW [N,K], db [N] or None).
     dgrad and wgrad are didi_gemm launches on transposed operand planes; db is a column sum."""
     pd = plane_dtype(precision)
     dC, A, W = _f32c(dC), _f32c(A), _f32c(W)
@@ -325,8 +325,123 @@ def linear_backward(dC, A, W, precision="bf16x3"):
         z = torch.zeros((M, pad), dtype=torch.float32, device=dC.device)
         z[:, :N] = dC
         dc_hi, dc_lo = split(z, dtype=pd)
-    _, _, dA = gemm(dc_hi, dc_lo, wt_hi, wt_lo, precision=precision, out_f32=True, out_planes=False)
+    dA = gemm(dc_hi, dc_lo, wt_hi, wt_lo, precision=precision, out_f32=True, out_planes=False)[2] if need_dA else None
     dct_hi, dct_lo = transpose_split(dC, dtype=pd)       # [N, M8]
     at_hi, at_lo = transpose_split(A, dtype=pd)          # [K, M8]
     _, _, dW = gemm(dct_hi, dct_lo, at_hi, at_lo, precision=precision, out_f32=True, out_planes=False)
-    return dA, dW, colsum(dC)
+    return dA, dW, (colsum(dC) if bias else None)
+
+
+def act_backward(act, dy, saved):
+    """dx = dy * act'(.): act "gelu" takes the PRE-activation, "tanh" the OUTPUT."""
+    dy, saved = _f32c(dy), _f32c(saved)
+    assert dy.shape == saved.shape
+    dx = torch.empty_like(dy)
+    _lib.check(lib.didi_act_backward(ACTS[act], dy.data_ptr(), saved.data_ptr(), dy.numel(), dx.data_ptr(), _lib.current_stream()),
+               "act_backward")
+    return dx
+
+
+def axpby(a, x, b, y):
+    """y <- a x + b y in place (fp32, contiguous, same shape)."""
+    assert x.shape == y.shape and x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype == torch.float32
+    _lib.check(lib.didi_axpby(float(a), x.data_ptr(), float(b), y.data_ptr(), x.numel(), _lib.current_stream()), "axpby")
+    return y
+
+
+def ce_backward(logits, targets, mask, scale):
+    """In place: logits [M, V] fp32 <- scale (softmax - onehot) on rows with mask != 0, zero elsewhere.
+    -> (the same tensor, nll fp32 [M]: the per-token cross-entropy terms, 0 on masked rows)."""
+    M, V = logits.shape
+    assert logits.is_contiguous() and logits.dtype == torch.float32
+    targets = targets.reshape(-1).to(torch.int64).contiguous()
+    mask = mask.reshape(-1).to(torch.int64).contiguous()
+    nll = torch.empty(M, dtype=torch.float32, device=logits.device)
+    _lib.check(lib.didi_ce_backward(logits.data_ptr(), targets.data_ptr(), mask.data_ptr(), M, V, float(scale), nll.data_ptr(),
+                                    _lib.current_stream()), "ce_backward")
+    return logits, nll
+
+
+def act_forward(act, x, dtype=torch.bfloat16, f32=True):
+    """act(x) -> (hi, lo, y fp32): "gelu" (exact erf form) or "tanh"."""
+    x = _f32c(x)
+    hi, lo = torch.empty_like(x, dtype=dtype), torch.empty_like(x, dtype=dtype)
+    y = torch.empty_like(x) if f32 else None
+    _lib.check(lib.didi_act_forward(ACTS[act], x.data_ptr(), x.numel(), _lib.ptr(y), hi.data_ptr(), lo.data_ptr(), _fmt(dtype),
+                                    _lib.current_stream()), "act_forward")
+    return hi, lo, y
+
+
+def embedding_backward(ids, dy, grad, scale=1.0, skip_id=-1):
+    """grad[ids[m], :] += scale * dy[m, :] (fp32 atomics); rows with id == skip_id get nothing."""
+    ids = ids.reshape(-1).to(torch.int64).contiguous()
+    dy = _f32c(dy)
+    H = dy.shape[-1]
+    assert grad.is_contiguous() and grad.dtype == torch.float32 and grad.shape[-1] == H and dy.numel() == ids.numel() * H
+    _lib.check(lib.didi_embedding_backward(ids.data_ptr(), dy.data_ptr(), ids.numel(), H, float(scale), int(skip_id), grad.data_ptr(),
+                                           _lib.current_stream()), "embedding_backward")
+    return grad
+
+
+def attention_backward(q, k, v, dO, heads, causal=False, key_mask=None, scale=None, out=None):
+    """fp32 q [B,Sq,heads*D], k/v [B,Sk,heads*D] (row-strided views of a fused projection are fine), dO [B,Sq,heads*D] contiguous
+    -> (dq, dk, dv).  ``out``: views to write into, strided exactly like q, k, v (e.g. the thirds of one [B,S,3H] buffer, which
+    is then the gradient of the fused projection's output); default: fresh contiguous tensors (needs contiguous q, k, v)."""
+    B, Sq, HD = q.shape
+    Sk = k.shape[1]
+    dO = _f32c(dO)
+    if out is None:
+        out = tuple(torch.empty(t_.shape, dtype=torch.float32, device=q.device) for t_ in (q, k, v))
+    for t_, g_, s in ((q, out[0], Sq), (k, out[1], Sk), (v, out[2], Sk)):
+        assert t_.dtype == torch.float32 and t_.stride(2) == 1 and t_.stride(0) == s * t_.stride(1), "operands must be [B*S, ld] row-major"
+        assert g_.dtype == torch.float32 and g_.stride() == t_.stride() and g_.shape == t_.shape, "gradients are laid out like their operands"
+    _lib.check(lib.didi_attention_backward(q.data_ptr(), k.data_ptr(), v.data_ptr(), dO.data_ptr(), _lib.ptr(key_mask), B, heads, Sq, Sk,
+                                           HD // heads, q.stride(1), k.stride(1), v.stride(1), HD, int(causal),
+                                           0.0 if scale is None else float(scale), out[0].data_ptr(), out[1].data_ptr(),
+                                           out[2].data_ptr(), _lib.current_stream()), "attention_backward")
+    return out
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gscale=None):
+    """torch.optim.AdamW on one fp32 tensor, in place; gradient pre-scaled by the device scalar ``gscale`` (clipping)."""
+    for t_ in (p, g, m, v):
+        assert t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == p.numel()
+    _lib.check(lib.didi_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1), float(beta2),
+                                   float(eps), float(weight_decay), int(step), _lib.ptr(gscale), _lib.current_stream()), "adamw_step")
+
+
+def sumsq_accumulate(x, out):
+    """out[0] += sum x^2."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.dtype == torch.float32
+    _lib.check(lib.didi_sumsq_accumulate(x.data_ptr(), x.numel(), out.data_ptr(), _lib.current_stream()), "sumsq")
+
+
+def train_embed_sum(x_t, time_embeds, t, pos_emb, tok0):
+    """x_t + time_embeds[t_b] + pos[s] + tok0 -> fp32 [B,S,H] (the decoder-embeddings LayerNorm input)."""
+    x_t = _f32c(x_t)
+    B, S, H = x_t.shape
+    t = t.reshape(-1).to(torch.int64).contiguous()
+    assert t.numel() == B and pos_emb.shape[0] >= S
+    out = torch.empty_like(x_t)
+    _lib.check(lib.didi_train_embed_sum(x_t.data_ptr(), time_embeds.data_ptr(), t.data_ptr(), pos_emb.data_ptr(), tok0.data_ptr(), B, S, H,
+                                        out.data_ptr(), _lib.current_stream()), "train_embed_sum")
+    return out
+
+
+def seq_sum(x):
+    x = _f32c(x)
+    B, S, H = x.shape
+    out = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    _lib.check(lib.didi_seq_sum(x.data_ptr(), B, S, H, out.data_ptr(), _lib.current_stream()), "seq_sum")
+    return out
+
+
+def train_target_backward(x0hat, emb, x0, mask, w_emb, w_x0, w_T, c_b, dxt, extra=None):
+    B, S, H = x0hat.shape
+    out = torch.empty_like(x0hat)
+    mask = mask.to(torch.int64).contiguous()
+    _lib.check(lib.didi_train_target_backward(_f32c(x0hat).data_ptr(), _f32c(emb).data_ptr(), _f32c(x0).data_ptr(), mask.data_ptr(),
+                                              float(w_emb), float(w_x0), float(w_T), _f32c(c_b).data_ptr(), _f32c(dxt).data_ptr(),
+                                              _lib.ptr(None if extra is None else _f32c(extra)), B, S, H, out.data_ptr(),
+                                              _lib.current_stream()), "train_target_backward")
+    return out

@@ -1,0 +1,401 @@
+"""``DiDi.training_step`` + ``configure_optimizers`` on the HIP path: forward, backward, gradient all-reduce, AdamW.
+
+Reference: src/diffusion/model.py:200-243 (training_step), :136-158 (AdamW(lr=1) x LambdaLR), :271-308 (the two LR lambdas),
+configs/train.yaml:33-45 (optimizer block, gradient_clip_val), src/training.py:37 (DDP: gradient all-reduce, mean).
+The backward is written out by hand (no autograd): every piece is a libdidi_hip kernel --
+  * Linear: dgrad and wgrad are MFMA GEMMs on transposed split planes, the bias gradient a column sum (ops.linear_backward);
+  * LayerNorm, GELU, tanh, softmax cross-entropy, embedding scatter-add, attention (probabilities recomputed): train.hip;
+torch owns the memory and does the B-element scalar arithmetic (per-dialog means, the clipping coefficient).
+What is trained: everything but the frozen context encoder (model.py:114-115): emb, time_embeds, classifier (or tied), adapter,
+the decoder.  ``decoder.embeddings.word_embeddings`` and ``decoder.pooler`` never receive a gradient in the reference (inputs
+arrive as ``inputs_embeds``; the pooler output is unused), AdamW skips them, and so does this trainer.
+Dropout: the decoder's hidden / attention-probability dropout (configs/train.yaml:22-23) is NOT applied (p = 0, the setting the
+gradient fixtures in tests/golden/train_tiny_* were made with); see DESIGN.md section 8.
+"""
+import math
+
+import torch
+
+from . import _lib, ops
+from .model import DiDiSampler
+
+
+def lr_linear(step, max_lr, min_lr, warmup, decay_range):
+    """src/diffusion/model.py:300-308."""
+    if min_lr is None:
+        raise ValueError("min_lr must be set for the linear scheduler")
+    if step < warmup:
+        return max_lr
+    if step > decay_range:
+        return min_lr
+    return (max_lr - min_lr) * (decay_range - step) / (decay_range - warmup) + min_lr
+
+
+def lr_rsqrt_with_warmup(step, max_lr, min_lr, warmup):
+    """src/diffusion/model.py:271-297."""
+    if warmup != 0 and step < warmup:
+        return max_lr * math.sqrt(step / warmup)
+    lr = max_lr * math.sqrt(1 / step) if warmup == 0 else max_lr * math.sqrt(warmup / step)
+    return max(lr, min_lr) if min_lr is not None else lr
+
+
+DEFAULT_OPT = dict(weight_decay=0.01, scheduler="linear", lr=1e-4, warmup_steps=2500, min_lr=0.0, decay_range=100_000)  # train.yaml:33-39
+
+
+class _W:
+    """One Linear of the trained graph: fp32 master weight/bias (views into the trainer's parameter dict) + split planes."""
+
+    def __init__(self, weights, biases, pd):
+        self.weights, self.biases, self.pd = weights, biases, pd
+        self.refresh()
+
+    def refresh(self):
+        self.w = self.weights[0] if len(self.weights) == 1 else torch.cat(self.weights, 0)
+        self.b = None if self.biases is None else (self.biases[0] if len(self.biases) == 1 else torch.cat(self.biases, 0))
+        self.hi, self.lo = ops.split(self.w, dtype=self.pd)
+
+
+class DiDiTrainer:
+    """Holds the fp32 master parameters under the reference's state-dict names and runs training steps on them.
+
+    ``precision``: bf16x3 (fp32-class: what the gradient fixtures are checked in) | fp16x2 | fp16 | bf16 for the decoder GEMMs of
+    forward and backward; the frozen encoder always runs bf16x3."""
+
+    def __init__(self, state_dict, cfg, device="cuda", precision="bf16x3", anchor_loss=False, noise_factor=1.0, opt_kwargs=None,
+                 gradient_clip_val=1.0):
+        self.cfg, self.device, self.precision = cfg, torch.device(device), precision
+        self.anchor_loss, self.noise_factor = bool(anchor_loss), float(noise_factor)
+        self.opt = dict(DEFAULT_OPT, **(opt_kwargs or {}))
+        self.clip = gradient_clip_val
+        self.frozen = DiDiSampler(state_dict, cfg, device=device, precision="bf16x3")  # context encoder, schedule buffers
+        self.sigmas, self.std_0, self.T = self.frozen.sigmas, self.frozen.std_0, cfg.diffusion_steps
+        self._pd = ops.plane_dtype(precision)
+        self._state_extra = {k: v for k, v in state_dict.items() if k.startswith("encoder.") or k in ("sigmas", "std_0")
+                             or k.startswith("decoder.pooler.") or k == "decoder.embeddings.word_embeddings.weight"
+                             or k == "decoder.embeddings.position_ids"}
+        f = lambda k: state_dict[k].detach().to(device=self.device, dtype=torch.float32).contiguous().clone()  # noqa: E731
+        P = {}
+        names = ["emb.weight", "time_embeds.weight", "decoder.embeddings.position_embeddings.weight",
+                 "decoder.embeddings.token_type_embeddings.weight", "decoder.embeddings.LayerNorm.weight", "decoder.embeddings.LayerNorm.bias"]
+        if not cfg.tie_weights:
+            names.append("classifier.weight")
+        if cfg.has_adapter:
+            names += ["adapter.0.weight", "adapter.0.bias", "adapter.2.weight", "adapter.2.bias"]
+        self._layer_names = []
+        for i in range(cfg.dec_layers):
+            p = f"decoder.encoder.layer.{i}."
+            ln = dict(
+                q=p + "attention.self.query", k=p + "attention.self.key", v=p + "attention.self.value", o=p + "attention.output.dense",
+                ln1=p + "attention.output.LayerNorm", cq=p + "crossattention.self.query", ck=p + "crossattention.self.key",
+                cv=p + "crossattention.self.value", co=p + "crossattention.output.dense", ln2=p + "crossattention.output.LayerNorm",
+                up=p + "intermediate.dense", down=p + "output.dense", ln3=p + "output.LayerNorm")
+            self._layer_names.append(ln)
+            for v in ln.values():
+                names += [v + ".weight", v + ".bias"]
+        for n in names:
+            P[n] = f(n)
+        self.params = P
+        self.m = {k: torch.zeros_like(v) for k, v in P.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in P.items()}
+        self.step_count = 0
+        self._build_linears()
+
+    # ------------------------------------------------------------------ parameter views
+    def _build_linears(self):
+        P, pd = self.params, self._pd
+        W = lambda *ns: _W([P[n + ".weight"] for n in ns], [P[n + ".bias"] for n in ns], pd)  # noqa: E731
+        self._lin = []
+        for ln in self._layer_names:
+            self._lin.append(dict(qkv=W(ln["q"], ln["k"], ln["v"]), o=W(ln["o"]), cq=W(ln["cq"]), ckv=W(ln["ck"], ln["cv"]), co=W(ln["co"]),
+                                  up=W(ln["up"]), down=W(ln["down"])))
+        self._cls = _W([P["emb.weight" if self.cfg.tie_weights else "classifier.weight"]], None, pd)
+        if self.cfg.has_adapter:
+            self._ad0, self._ad2 = W("adapter.0"), W("adapter.2")
+
+    def refresh_planes(self):
+        """Re-split every weight after the optimiser moved the fp32 masters."""
+        for d in self._lin:
+            for w in d.values():
+                w.refresh()
+        self._cls.refresh()
+        if self.cfg.has_adapter:
+            self._ad0.refresh()
+            self._ad2.refresh()
+
+    def state_dict(self):
+        """The reference's checkpoint key layout: trained tensors + the untouched rest."""
+        sd = dict(self._state_extra)
+        sd.update({k: v.detach().clone() for k, v in self.params.items()})
+        if self.cfg.tie_weights:
+            sd["classifier.weight"] = sd["emb.weight"]
+        return sd
+
+    def sampler(self, **kw):
+        """A DiDiSampler on the current weights (validation_step's ``sample``)."""
+        return DiDiSampler(self.state_dict(), self.cfg, device=self.device, **kw)
+
+    # ------------------------------------------------------------------ forward + backward
+    def _linear(self, w, a_hi, a_lo, **kw):
+        return ops.gemm(a_hi, a_lo, w.hi, w.lo, bias=w.b, precision=self.precision, out_f32=True, **kw)
+
+    def _linear_bwd(self, dC, A, w):
+        return ops.linear_backward(dC, A, w.w, precision=self.precision)
+
+    @torch.no_grad()
+    def forward_backward(self, raw_context, target, *, draws=None, t=None, keep=False):
+        """One ``training_step`` and its backward -> dict(mse, ce, t_T, loss, ce_hat [0-dim device tensors], grads {name: fp32}).
+
+        ``draws`` / ``t``: injected normal draws [n0, n1] and timesteps (parity tests), else Philox noise / ``torch.randint`` as
+        the reference draws them.  ``keep``: also return the tensors the tests compare (x_0, x_t, x_0_hat, d x_0_hat)."""
+        cfg, dev, P = self.cfg, self.device, self.params
+        ids, tmask = target.input_ids.to(dev), target.attention_mask.to(dev)
+        cids, cmask = raw_context.input_ids.to(dev), raw_context.attention_mask.to(dev)
+        B, S = ids.shape
+        Cn = cids.shape[1]
+        H, T, A = cfg.dec_dim, self.T, cfg.dec_heads
+        M = B * S
+        eps = cfg.dec_ln_eps
+        pd = self._pd
+        G = {}
+        # ---- noising (model.py:202-207)
+        emb = ops.embed_gather(ids, P["emb.weight"])
+        seed = 0
+        if draws is None:
+            seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+        if t is None:
+            t = torch.randint(1, T + 1, size=(B, 1), device=dev)
+        t = t.to(dev)
+        sigma = self.sigmas[t.view(-1)]
+        s_b = (sigma * self.noise_factor ** 2).contiguous()
+        c_b = (1.0 / torch.sqrt(sigma * sigma + 1.0)).contiguous()
+        n0 = n1 = None
+        if draws is not None:
+            n0, n1 = draws[0].to(dev).float().contiguous(), draws[1].to(dev).float().contiguous()
+        x_0, x_t = ops.train_noise(emb, s_b, c_b, self.std_0, n0, n1, seed=seed)
+        # ---- context: frozen encoder, trainable adapter (model.py:165-170, 183-188)
+        c_hi, c_lo, enc = self.frozen._encode_raw(cids, cmask)
+        mask32 = cmask.to(torch.int32).contiguous()
+        if cfg.has_adapter:
+            if pd != torch.bfloat16:
+                c_hi, c_lo = ops.split(enc, dtype=pd)
+            z_hi, z_lo, z = self._linear(self._ad0, c_hi, c_lo, act="tanh")
+            x_hi, x_lo, ctx = self._linear(self._ad2, z_hi, z_lo)
+        else:
+            ctx = enc
+            x_hi, x_lo = (c_hi, c_lo) if pd == torch.bfloat16 else ops.split(enc, dtype=pd)
+        # ---- decoder forward, activations kept in fp32 for the backward
+        x_in = ops.train_embed_sum(x_t, P["time_embeds.weight"], t, P["decoder.embeddings.position_embeddings.weight"],
+                                   P["decoder.embeddings.token_type_embeddings.weight"][0].contiguous())
+        h_hi, h_lo, h = ops.layernorm(x_in.view(M, H), P["decoder.embeddings.LayerNorm.weight"], P["decoder.embeddings.LayerNorm.bias"], eps,
+                                      f32=True, dtype=pd)
+        saved = []
+        x3 = self.precision in ("bf16x3", "fp16x3")
+        ap = self.precision  # attention precision
+        for li, (L, ln) in enumerate(zip(self._lin, self._layer_names)):
+            s = dict(h0=h)
+            qkv_hi, qkv_lo, qkv = self._linear(L["qkv"], h_hi, h_lo)
+            v3 = lambda t_, i: None if t_ is None else t_.view(B, S, 3 * H)[:, :, i * H:(i + 1) * H]  # noqa: E731
+            a_hi, a_lo = ops.attention(*(((v3(qkv_hi, i), v3(qkv_lo, i))) for i in range(3)), A, causal=True, precision=ap)
+            a_hi = a_hi.view(M, H)
+            a_lo = None if a_lo is None else a_lo.view(M, H)
+            s["qkv"], s["att"] = qkv, ops.join(a_hi, a_lo)
+            _, _, s1 = self._linear(L["o"], a_hi, a_lo if a_lo is not None else None, residual=h, out_planes=False)
+            h_hi, h_lo, h1 = ops.layernorm(s1, P[ln["ln1"] + ".weight"], P[ln["ln1"] + ".bias"], eps, f32=True, dtype=pd)
+            s["s1"], s["h1"] = s1, h1
+            cq_hi, cq_lo, cq = self._linear(L["cq"], h_hi, h_lo)
+            ckv_hi, ckv_lo, ckv = self._linear(L["ckv"], x_hi, x_lo)
+            v2 = lambda t_, i: None if t_ is None else t_.view(B, Cn, 2 * H)[:, :, i * H:(i + 1) * H]  # noqa: E731
+            ca_hi, ca_lo = ops.attention((cq_hi.view(B, S, H), cq_lo.view(B, S, H)), (v2(ckv_hi, 0), v2(ckv_lo, 0)),
+                                         (v2(ckv_hi, 1), v2(ckv_lo, 1)), A, causal=False, key_mask=mask32, precision=ap)
+            ca_hi = ca_hi.view(M, H)
+            ca_lo = None if ca_lo is None else ca_lo.view(M, H)
+            s["cq"], s["ckv"], s["catt"] = cq, ckv, ops.join(ca_hi, ca_lo)
+            _, _, s2 = self._linear(L["co"], ca_hi, ca_lo, residual=h1, out_planes=False)
+            h_hi, h_lo, h2 = ops.layernorm(s2, P[ln["ln2"] + ".weight"], P[ln["ln2"] + ".bias"], eps, f32=True, dtype=pd)
+            s["s2"], s["h2"] = s2, h2
+            _, _, u = self._linear(L["up"], h_hi, h_lo, out_planes=False)
+            f_hi, f_lo, f_ = self._gelu_planes(u)
+            s["u"], s["f"] = u, f_
+            _, _, s3 = self._linear(L["down"], f_hi, f_lo, residual=h2, out_planes=False)
+            h_hi, h_lo, h = ops.layernorm(s3, P[ln["ln3"] + ".weight"], P[ln["ln3"] + ".bias"], eps, f32=True, dtype=pd)
+            s["s3"] = s3
+            saved.append(s)
+        x_0_hat = h.view(B, S, H)
+        # ---- losses (model.py:216-243)
+        sums = ops.train_loss_terms(x_0_hat, emb, x_0, tmask)
+        p = (t.view(-1) == 1).float().mean()
+        per = sums / float(S * H)
+        mse = p * per[:, 0].mean() + (1.0 - p) * per[:, 1].mean()
+        sigma_T = self.sigmas[-1]
+        t_T = sums[:, 2].sum() / (sigma_T * sigma_T + 1.0) / float(B * S * H)
+        n_tok = tmask.sum()
+        n_tok_f = float(n_tok.item())
+        # Loss scale of the backward: every loss weight carries a 1 / (B S H) or 1 / tokens, which puts the gradients of the
+        # activations near fp16's subnormals.  fp16-plane precisions run the backward on `ls` x the loss (a power of two, so
+        # exact) and the parameter gradients are scaled back at the end; bf16 planes have fp32's exponent range (ls = 1).
+        ls = 2.0 ** round(math.log2(B * S * H)) if pd == torch.float16 else 1.0
+
+        def logits_of(x2d):
+            hi, lo = ops.split(x2d, dtype=pd)
+            _, _, lg = ops.gemm(hi, lo, self._cls.hi, self._cls.lo, precision=self.precision, out_f32=True, out_planes=False)
+            return lg
+
+        def ce_and_grad(x2d):
+            """cross-entropy of classifier(x) and, in place of the logits, its gradient with respect to them."""
+            lg = logits_of(x2d)
+            _, nll = ops.ce_backward(lg, ids, tmask, ls / n_tok_f)
+            return nll.sum() / n_tok_f, lg
+
+        hat2d = x_0_hat.reshape(M, H)
+        if self.anchor_loss:
+            ce, dlg = ce_and_grad(hat2d)
+            ce_hat = ce
+            d_hat_ce, dWc, _ = ops.linear_backward(dlg, hat2d, self._cls.w, precision=self.precision, bias=False)
+            extra = None
+        else:
+            ce, dlg = ce_and_grad(x_0.reshape(M, H))
+            extra, dWc, _ = ops.linear_backward(dlg, x_0.reshape(M, H), self._cls.w, precision=self.precision, bias=False)
+            hi, lo = ops.split(hat2d, dtype=pd)
+            _, nll = ops.round_ce(hi, lo if x3 else None, self._cls.hi, self._cls.lo, ids, self.precision)
+            m = tmask.reshape(-1).to(nll.dtype)
+            ce_hat = (nll * m).sum() / m.sum()
+            d_hat_ce = None
+        del dlg
+        loss = mse + ce if self.anchor_loss else mse + ce + t_T
+        # ---- backward
+        pf = float(p.item())
+        w_emb, w_x0 = ls * 2.0 * pf / (B * S * H), ls * 2.0 * (1.0 - pf) / (B * S * H)
+        w_T = 0.0 if self.anchor_loss else ls * 2.0 / ((float(sigma_T) ** 2 + 1.0) * B * S * H)
+        dh = ops.train_mse_backward(x_0_hat, emb, x_0, tmask, w_emb, w_x0).view(M, H)
+        if d_hat_ce is not None:
+            ops.axpby(1.0, d_hat_ce, 1.0, dh)
+        d_x0_hat = dh.clone() if keep else None
+        dctx = torch.zeros((B * Cn, H), dtype=torch.float32, device=dev) if cfg.has_adapter else None
+        for li in reversed(range(cfg.dec_layers)):
+            L, ln, s = self._lin[li], self._layer_names[li], saved[li]
+
+            def put(name, dw, db):
+                G[name + ".weight"], G[name + ".bias"] = dw, db
+
+            ds3, dg, db = ops.layernorm_backward(dh, s["s3"], P[ln["ln3"] + ".weight"], eps)
+            put(ln["ln3"], dg, db)
+            df, dW, dbias = self._linear_bwd(ds3, s["f"], L["down"])
+            put(ln["down"], dW, dbias)
+            du = ops.act_backward("gelu", df, s["u"])
+            dh2, dW, dbias = self._linear_bwd(du, s["h2"], L["up"])
+            put(ln["up"], dW, dbias)
+            ops.axpby(1.0, ds3, 1.0, dh2)
+            ds2, dg, db = ops.layernorm_backward(dh2, s["s2"], P[ln["ln2"] + ".weight"], eps)
+            put(ln["ln2"], dg, db)
+            dcatt, dW, dbias = self._linear_bwd(ds2, s["catt"], L["co"])
+            put(ln["co"], dW, dbias)
+            ckv = s["ckv"].view(B, Cn, 2 * H)
+            dckv = torch.empty_like(ckv)
+            dcq = torch.empty((B, S, H), dtype=torch.float32, device=dev)
+            ops.attention_backward(s["cq"].view(B, S, H), ckv[:, :, :H], ckv[:, :, H:], dcatt.view(B, S, H), A, causal=False, key_mask=mask32,
+                                   out=(dcq, dckv[:, :, :H], dckv[:, :, H:]))
+            dh1, dW, dbias = self._linear_bwd(dcq.view(M, H), s["h1"], L["cq"])
+            put(ln["cq"], dW, dbias)
+            ops.axpby(1.0, ds2, 1.0, dh1)
+            dctx_l, dW, dbias = self._linear_bwd(dckv.view(B * Cn, 2 * H), ctx.view(B * Cn, H), L["ckv"])
+            put(ln["ck"], dW[:H].contiguous(), dbias[:H].contiguous())
+            put(ln["cv"], dW[H:].contiguous(), dbias[H:].contiguous())
+            if dctx is not None:
+                ops.axpby(1.0, dctx_l, 1.0, dctx)
+            ds1, dg, db = ops.layernorm_backward(dh1, s["s1"], P[ln["ln1"] + ".weight"], eps)
+            put(ln["ln1"], dg, db)
+            datt, dW, dbias = self._linear_bwd(ds1, s["att"], L["o"])
+            put(ln["o"], dW, dbias)
+            qkv = s["qkv"].view(B, S, 3 * H)
+            dqkv = torch.empty_like(qkv)
+            ops.attention_backward(qkv[:, :, :H], qkv[:, :, H:2 * H], qkv[:, :, 2 * H:], datt.view(B, S, H), A, causal=True,
+                                   out=(dqkv[:, :, :H], dqkv[:, :, H:2 * H], dqkv[:, :, 2 * H:]))
+            dh0, dW, dbias = self._linear_bwd(dqkv.view(M, 3 * H), s["h0"], L["qkv"])
+            for j, key in enumerate(("q", "k", "v")):
+                put(ln[key], dW[j * H:(j + 1) * H].contiguous(), dbias[j * H:(j + 1) * H].contiguous())
+            ops.axpby(1.0, ds1, 1.0, dh0)
+            dh = dh0
+            saved[li] = None  # free this layer's activations
+        # decoder embeddings
+        dx_in, dg, db = ops.layernorm_backward(dh, x_in.view(M, H), P["decoder.embeddings.LayerNorm.weight"], eps)
+        G["decoder.embeddings.LayerNorm.weight"], G["decoder.embeddings.LayerNorm.bias"] = dg, db
+        gpos = torch.zeros_like(P["decoder.embeddings.position_embeddings.weight"])
+        gpos[:S] = ops.colsum(dx_in.view(B, S * H)).view(S, H)
+        G["decoder.embeddings.position_embeddings.weight"] = gpos
+        gtok = torch.zeros_like(P["decoder.embeddings.token_type_embeddings.weight"])
+        gtok[0] = ops.colsum(dx_in.view(M, H))
+        G["decoder.embeddings.token_type_embeddings.weight"] = gtok
+        gte = torch.zeros_like(P["time_embeds.weight"])
+        ops.embedding_backward(t.view(-1), ops.seq_sum(dx_in.view(B, S, H)), gte)
+        G["time_embeds.weight"] = gte
+        # target embeddings: mse (both branches), t_T, x_t, cross-entropy on classifier(x_0)
+        d_emb = ops.train_target_backward(x_0_hat, emb, x_0, tmask, w_emb, w_x0, w_T, c_b, dx_in.view(B, S, H),
+                                          None if extra is None else extra.view(B, S, H))
+        gemb = torch.zeros_like(P["emb.weight"])
+        ops.embedding_backward(ids, d_emb, gemb, skip_id=cfg.pad_idx)
+        if cfg.tie_weights:
+            ops.axpby(1.0, dWc, 1.0, gemb)
+        else:
+            G["classifier.weight"] = dWc
+        G["emb.weight"] = gemb
+        # adapter (model.py:122-123)
+        if cfg.has_adapter:
+            dz, dW, dbias = self._linear_bwd(dctx, z, self._ad2)
+            G["adapter.2.weight"], G["adapter.2.bias"] = dW, dbias
+            dpre = ops.act_backward("tanh", dz, z)
+            _, dW, dbias = ops.linear_backward(dpre, enc, self._ad0.w, precision=self.precision, need_dA=False)
+            G["adapter.0.weight"], G["adapter.0.bias"] = dW, dbias
+        if ls != 1.0:
+            for g_ in G.values():
+                ops.axpby(0.0, g_, 1.0 / ls, g_)
+        out = dict(mse=mse, ce=ce, t_T=t_T, loss=loss, ce_hat=ce_hat, grads=G, t=t)
+        if keep:
+            out.update(emb=emb, x_0=x_0, x_t=x_t, x_0_hat=x_0_hat, d_x_0_hat=d_x0_hat.view(B, S, H) / ls)
+        return out
+
+    def _gelu_planes(self, u):
+        """gelu(u) as planes + fp32: the exact erf form of the GEMM epilogue, here as its own pass because the backward keeps
+        the PRE-activation."""
+        return ops.act_forward("gelu", u, dtype=self._pd)
+
+    # ------------------------------------------------------------------ optimiser (model.py:136-158, train.yaml:33-45)
+    def lr_at(self, step):
+        o = self.opt
+        if o["scheduler"] == "linear":
+            return lr_linear(step, o["lr"], o["min_lr"], o["warmup_steps"], o["decay_range"])
+        return lr_rsqrt_with_warmup(step, o["lr"], o["min_lr"], o["warmup_steps"])
+
+    @torch.no_grad()
+    def optimizer_step(self, grads):
+        """Clip the global gradient norm to ``gradient_clip_val`` (Lightning's clip_grad_norm_: coefficient
+        min(1, clip / (norm + 1e-6))), then AdamW(lr = 1 x lambda(step), betas (0.9, 0.999), eps 1e-8) on every parameter.
+        LambdaLR semantics: the k-th optimizer.step() (k = 1, 2, ...) runs with lambda(k - 1).  -> gradient norm (device)."""
+        lr = self.lr_at(self.step_count)
+        self.step_count += 1
+        total = torch.zeros(1, dtype=torch.float32, device=self.device)
+        for k in self.params:
+            ops.sumsq_accumulate(grads[k], total)
+        norm = total.sqrt()
+        gscale = None
+        if self.clip is not None:
+            gscale = torch.clamp(float(self.clip) / (norm + 1e-6), max=1.0)
+        for k, p_ in self.params.items():
+            ops.adamw_step(p_, grads[k], self.m[k], self.v[k], lr, 0.9, 0.999, 1e-8, self.opt["weight_decay"], self.step_count, gscale)
+        self.refresh_planes()
+        return norm
+
+    def training_step(self, raw_context, target, world=None, **kw):
+        """forward + backward + (``world`` = a torch.distributed group or True: bucketed gradient all-reduce with the five logged
+        scalars folded into the last bucket, src/training.py:37 + model.py:241-242) + optimiser step -> the five scalars."""
+        from . import dist as ddist
+        from .training import metric_message
+
+        out = self.forward_backward(raw_context, target, **kw)
+        metrics = metric_message(out)
+        if world is not None and world is not False:
+            names = list(self.params)
+            grads, metrics = ddist.allreduce_gradients([out["grads"][k] for k in names], None if world is True else world, metrics)
+            out["grads"] = dict(zip(names, grads))
+        out["grad_norm"] = self.optimizer_step(out["grads"])
+        out["metrics"] = metrics
+        return out

@@ -494,6 +494,43 @@ int didi_colsum(const float* x, int M, int N, float* out, void* workspace, void*
 /* fp32 src [R, C] -> split planes of its transpose [C, ldo], ldo >= R (columns R..ldo-1 zero: pads the GEMM's K to % 8). */
 int didi_transpose_split(const float* src, int R, int C, int ldo, uint16_t* hi, uint16_t* lo, int plane_format, void* stream);
 
+/* y = act(x) (fp32, nullable) + its split planes (nullable): the training forward keeps the pre-activation, so GELU is its own
+ * pass there.  dx = dy * act'(.) for the two activations on the trained path: DIDI_ACT_GELU takes the PRE-activation (BertIntermediate,
+ * HF:models/bert/modeling_bert.py:335-336), DIDI_ACT_TANH the OUTPUT (the adapter's Tanh, src/diffusion/model.py:123). n % 4 == 0. */
+int didi_act_forward(int act, const float* x, size_t n, float* y, void* hi, void* lo, int plane_format, void* stream);
+int didi_act_backward(int act, const float* dy, const float* saved, size_t n, float* dx, void* stream);
+/* y = a x + b y (gradient accumulation where paths meet: residual connections, x_0's consumers). n % 4 == 0. */
+int didi_axpby(float a, const float* x, float b, float* y, size_t n, void* stream);
+/* calculate_batch_ce backward (src/metrics.py:91-93) on MATERIALISED logits fp32 [M, V], in place:
+ * logits[m, :] <- w_m (softmax(logits[m, :]) - onehot(targets[m])), w_m = scale where mask[m] != 0 (scale = 1 / kept tokens), else 0. */
+/* nll (nullable) fp32 [M]: the per-token cross-entropy terms (0 on masked rows), from the same pass. */
+int didi_ce_backward(float* logits, const int64_t* targets, const int64_t* mask, int M, int V, float scale, float* nll, void* stream);
+/* nn.Embedding backward: grad[ids[m], :] += scale * dy[m, :] (float atomics); rows with id == skip_id (padding_idx) get none. */
+int didi_embedding_backward(const int64_t* ids, const float* dy, int M, int H, float scale, int64_t skip_id, float* grad, void* stream);
+/* Attention backward (fp32 operands addressed as didi_attention addresses its planes; P is recomputed): dQ, dK, dV from dO.
+ * Sq, Sk <= 96, D <= 64.  A correctness-level first version (fp32 FMA loops in LDS); the sampler never runs it. */
+int didi_attention_backward(const float* Q, const float* K, const float* V, const float* dO, const int32_t* key_mask, int B, int heads,
+                            int Sq, int Sk, int D, int ldq, int ldk, int ldv, int ldo, int causal, float scale, float* dQ, float* dK,
+                            float* dV, void* stream);
+/* torch.optim.AdamW step (src/diffusion/model.py:136-158: AdamW(lr = 1) x LambdaLR, so `lr` is the schedule's value) on one
+ * parameter tensor, gradient pre-scaled by *gscale (device scalar or NULL: the clipping coefficient, configs/train.yaml:45). */
+int didi_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int step, const float* gscale, void* stream);
+/* out[0] += sum x^2 (global gradient norm; the caller zeroes out). */
+int didi_sumsq_accumulate(const float* x, size_t n, float* out, void* stream);
+
+/* Decoder input of the training forward in fp32 (the LayerNorm INPUT, which the backward needs):
+ * out[b,s,:] = x_t[b,s,:] + time_embeds[t[b],:] + pos_emb[s,:] + tok0 (src/diffusion/model.py:190-191 + BertEmbeddings). t: int64 [B]. */
+int didi_train_embed_sum(const float* x_t, const float* time_embeds, const int64_t* t, const float* pos_emb, const float* tok0, int B, int S,
+                         int H, float* out, void* stream);
+/* out[b, :] = sum_s x[b, s, :] (fp32 [B,S,H] -> [B,H]): per-dialog sums that scatter into the time-embedding rows. */
+int didi_seq_sum(const float* x, int B, int S, int H, float* out, void* stream);
+/* Gradient arriving at the target embeddings (src/diffusion/model.py:202-235), one pass:
+ * out = m (-w_emb (x0hat - emb) - w_x0 (x0hat - x0) + w_T x0) + c_b[b] dxt + extra, with dxt the gradient of the decoder input x_t,
+ * extra (nullable) the gradient of x_0 from cross-entropy(classifier(x_0)); w_T = 2 / ((sigma_T^2 + 1) B S H) or 0 (anchor loss). */
+int didi_train_target_backward(const float* x0hat, const float* emb, const float* x0, const int64_t* mask, float w_emb, float w_x0, float w_T,
+                               const float* c_b, const float* dxt, const float* extra, int B, int S, int H, float* out, void* stream);
+
 /* hipEvent wrappers for the prof_events_host hook (bench.py): events must live in the HIP runtime
  * instance this library is bound to.  Host-side helpers, no reference counterpart.  Elapsed time
  * may only be read after the caller has synchronised the stream. */

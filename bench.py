@@ -139,6 +139,99 @@ def cpu_baseline(cfg, sd, ids, mask, S, n_calls_total, slice_dialogs=32, slice_c
     }
 
 
+def main_training(args):
+    """BASELINE configs[4]: 'Training step (noised-target fwd+bwd, MSE+rounding loss) DDP over 8 GPUs with RCCL gradient
+    all-reduce' -- one step = DiDi.training_step + backward + bucketed gradient all-reduce (the five logged scalars folded in)
+    + clip + AdamW on a fresh synthetic batch of 256 dialogs per GPU (configs/train.yaml:9)."""
+    from didi_amd import dist as ddist
+    from didi_amd.config import DiDiConfig
+    from didi_amd.synthetic import RawContext, synthetic_batch, synthetic_state_dict
+    from didi_amd.trainer import DiDiTrainer
+
+    rank, world, local_rank = ddist.init_from_env("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = torch.device("cuda", local_rank)
+    cfg = DiDiConfig(diffusion_steps=args.diffusion_steps, **({"vocab": args.vocab} if args.vocab else {}))
+    sd = synthetic_state_dict(cfg, seed=1234)
+    tr = DiDiTrainer(sd, cfg, device=dev, precision=args.train_precision)
+    B, S = args.batch, args.seq
+    n_batches = 4
+    batches = []
+    for i in range(n_batches):  # per-rank shards of distinct global batches, resident in HBM before the timed region
+        ids, mask = synthetic_batch(B * world, S, cfg.vocab, seed=0xBADB01 + i)
+        tids, tmask = synthetic_batch(B * world, S, cfg.vocab, seed=0xBADB01 + 100 + i)
+        lo = rank * B
+        batches.append((RawContext(ids[lo:lo + B].to(dev), mask[lo:lo + B].to(dev)), RawContext(tids[lo:lo + B].to(dev), tmask[lo:lo + B].to(dev))))
+    torch.manual_seed(0xBADB01 + rank)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def step(k):
+        c, t = batches[k % n_batches]
+        return tr.training_step(c, t, world=world)
+
+    losses = []
+    for k in range(max(args.warmup, 1 if world > 1 else 0)):
+        losses.append(step(k))
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        losses.append(step(k))
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    vals = [float(o["loss"]) for o in losses]
+    assert all(v == v and abs(v) < 1e6 for v in vals), f"non-finite loss: {vals}"
+    assert all(bool(torch.isfinite(p_).all()) for p_ in tr.params.values()), "non-finite parameters after the timed steps"
+    # phase breakdown of one more (untimed) step
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    c, t = batches[0]
+    ev[0].record()
+    out = tr.forward_backward(c, t)
+    ev[1].record()
+    tr.optimizer_step(out["grads"])
+    ev[2].record()
+    torch.cuda.synchronize()
+    M, H, I, L, V = B * S, cfg.dec_dim, cfg.dec_ffn, cfg.dec_layers, cfg.vocab
+    fwd = L * 2.0 * M * (3 * H * H + 3 * H * H + 2 * H * I) + L * 2.0 * (B * S) * 2 * H * H + 2.0 * M * V * H  # + ckv on context rows
+    gemm_flops = 3.0 * fwd  # forward + dgrad + wgrad
+    n_params = sum(p_.numel() for p_ in tr.params.values())
+    value = B * world * args.steps / elapsed
+    res = {
+        "metric": "training dialogs/sec (fwd + bwd + gradient all-reduce + AdamW, whole job)", "value": round(value, 2), "unit": "dialogs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 1),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"bf16x3": "bf16", "fp16x2": "fp16"}.get(args.train_precision, args.train_precision), "data": "synthetic",
+        "config": {
+            "workload": (f"BASELINE configs[4] (training step): blenderbot-400M-distill-sized frozen encoder + BertConfig-default decoder "
+                         f"(12x768/12h/3072), V={cfg.vocab}, T={cfg.diffusion_steps}, batch {B}/GPU, context {S}, target {S}, AdamW + linear LR + clip 1.0, "
+                         f"dropout 0 (the reference's train.yaml uses 0.1: not implemented, DESIGN.md section 8)"),
+            "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world} (bucketed gradient all-reduce + 5 metric scalars in the last bucket)",
+            "trainable_parameters": n_params, "precision": args.train_precision,
+            "world_size_seen": torch.distributed.get_world_size() if world > 1 else 1,
+            "backend": torch.distributed.get_backend() if world > 1 else None,
+            "losses_first_last": [round(vals[0], 4), round(vals[-1], 4)],
+            "phase_ms": {"forward_backward": round(ev[0].elapsed_time(ev[1]), 2), "clip_adamw_resplit": round(ev[1].elapsed_time(ev[2]), 2)},
+        },
+        "roofline": {"bound": "mfma", "kernel": "all GEMMs of the step (forward, dgrad, wgrad): whole-step figure, not a per-kernel one",
+                     "achieved": round(gemm_flops / (elapsed / args.steps) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(gemm_flops / (elapsed / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "note": "algorithmic GEMM FLOPs of one step (3 x forward) / the whole step time; the backward's attention and elementwise "
+                             "kernels are correctness-level this round (DESIGN.md section 8)"},
+    }
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,10 +250,14 @@ def main():
     ap.add_argument("--vocab", type=int, default=None, help="vocabulary size (BASELINE config 4: 50000)")
     ap.add_argument("--clamp", action="store_true", help="config 4's per-step clamp x0 <- emb[argmax(classifier(x0))] (not in the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--preset", default=None, choices=["configs1", "configs2", "configs3"],
+    ap.add_argument("--train-precision", default="bf16x3", choices=["bf16x3", "fp16x2", "fp16", "bf16"],
+                    help="--preset configs4 only: GEMM precision of the training step's forward and backward")
+    ap.add_argument("--preset", default=None, choices=["configs1", "configs2", "configs3", "configs4"],
                     help="BASELINE.json configs[i]: configs1 = the default (ddpm, f=1, 256/GPU); configs2 = 'DDIM 200-step, batch 4096 over "
                          "8 GPUs' = euler, step_freq 10, 512 dialogs/GPU; configs3 = V=50000, seq 84, batch 1024, per-step clamp")
     args = ap.parse_args()
+    if args.preset == "configs4":  # BASELINE configs[4]: the training step (secondary line; the headline metric is the sampler's)
+        return main_training(args)
     workload = "BASELINE configs[1]"
     if args.preset == "configs2":
         args.mode, args.freq, args.batch = "euler", 10, 512

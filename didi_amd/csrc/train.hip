@@ -185,12 +185,30 @@ __global__ void __launch_bounds__(256) layernorm_backward_kernel(const float* dy
     }
 }
 
-__global__ void __launch_bounds__(256) partial_rows_sum_kernel(const float* partial, int nblk, int stride, int W, float* out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= W) return;
-    float a = 0.f;
-    for (int b = 0; b < nblk; ++b) a += partial[(size_t)b * stride + n];
-    out[n] = a;
+// out[n] = sum_b partial[b, n] for n < W (and out2[n - W] for W <= n < 2W when out2 is given): 64 columns per workgroup, the
+// rows dealt over its four waves with four independent accumulators each (a serial 1024-term chain per column cost 140 us).
+__global__ void __launch_bounds__(256) partial_rows_sum_kernel(const float* partial, int nblk, int stride, int W, float* out, float* out2) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane, total = out2 ? 2 * W : W;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (n < total) {
+        int b = wave;
+        for (; b + 12 < nblk; b += 16) {
+            a0 += partial[(size_t)b * stride + n];
+            a1 += partial[(size_t)(b + 4) * stride + n];
+            a2 += partial[(size_t)(b + 8) * stride + n];
+            a3 += partial[(size_t)(b + 12) * stride + n];
+        }
+        for (; b < nblk; b += 4) a0 += partial[(size_t)b * stride + n];
+    }
+    red[wave][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wave == 0 && n < total) {
+        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (n < W) out[n] = v;
+        else out2[n - W] = v;
+    }
 }
 
 static int ln_bwd_blocks(int M) { return std::min(1024, cdiv(M, 4)); }
@@ -209,8 +227,7 @@ extern "C" int didi_layernorm_backward(const float* dy, const float* x, const fl
     else if (H <= 768) layernorm_backward_kernel<3><<<nblk, 256, 0, st>>>(dy, x, gamma, eps, M, H, dx, partial);
     else layernorm_backward_kernel<5><<<nblk, 256, 0, st>>>(dy, x, gamma, eps, M, H, dx, partial);
     DIDI_LAUNCH_CHECK();
-    partial_rows_sum_kernel<<<cdiv(H, 256), 256, 0, st>>>(partial, nblk, 2 * H, H, dgamma);
-    partial_rows_sum_kernel<<<cdiv(H, 256), 256, 0, st>>>(partial + H, nblk, 2 * H, H, dbeta);
+    partial_rows_sum_kernel<<<cdiv(2 * H, 64), 256, 0, st>>>(partial, nblk, 2 * H, H, dgamma, dbeta);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }
@@ -235,7 +252,7 @@ extern "C" int didi_colsum(const float* x, int M, int N, float* out, void* works
     hipStream_t st = as_stream(stream);
     colsum_partial_kernel<<<dim3(cdiv(N, 256), nb), 256, 0, st>>>(x, M, N, rpb, reinterpret_cast<float*>(workspace));
     DIDI_LAUNCH_CHECK();
-    partial_rows_sum_kernel<<<cdiv(N, 256), 256, 0, st>>>(reinterpret_cast<const float*>(workspace), nb, N, N, out);
+    partial_rows_sum_kernel<<<cdiv(N, 64), 256, 0, st>>>(reinterpret_cast<const float*>(workspace), nb, N, N, out, nullptr);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }
@@ -407,104 +424,211 @@ extern "C" int didi_embedding_backward(const int64_t* ids, const float* dy, int 
 }
 
 // ------------------------------------------------------------------ attention backward (fp32, one workgroup per (dialog, head))
-// O = softmax(Q K^T s + mask) V.  With P the probabilities and D_i = sum_j P_ij dP_ij (= dO_i . O_i):
+// O = softmax(Q K^T s + mask) V.  With P the probabilities and D_i = sum_j P_ij dP_ij:
 //   dV = P^T dO,  dP = dO V^T,  dS = P o (dP - D) s,  dQ = dS K,  dK = dS^T Q.
-// Everything of one head lives in LDS as fp32 (Sq, Sk <= 96, D <= 64: 4 x 24 KiB operands + 36 KiB of P): recomputes P from
-// Q and K instead of saving it.  Plain fp32 FMA loops -- a first, correctness-level version (the sampler never runs it).
-__global__ void __launch_bounds__(256) attention_backward_kernel(const float* Q, const float* K, const float* V, const float* dO,
-                                                                 const int32_t* key_mask, int heads, int Sq, int Sk, int D, int ldq,
-                                                                 int ldk, int ldv, int ldo, int causal, float scale, float* dQ,
-                                                                 float* dK, float* dV) {
-    extern __shared__ float sm[];
-    const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x;
-    float* q = sm;                 // [Sq][D]
-    float* k = q + Sq * D;         // [Sk][D]
-    float* v = k + Sk * D;         // [Sk][D]
-    float* g = v + Sk * D;         // dO [Sq][D]
-    float* P = g + Sq * D;         // [Sq][Sk] probabilities, then dS
-    float* Dr = P + Sq * Sk;       // [Sq]
-    for (int i = tid; i < Sq * D; i += 256) {
-        const int r = i / D, c = i % D;
-        q[i] = Q[((size_t)b * Sq + r) * ldq + h * D + c];
-        g[i] = dO[((size_t)b * Sq + r) * ldo + h * D + c];
-    }
-    for (int i = tid; i < Sk * D; i += 256) {
-        const int r = i / D, c = i % D;
-        k[i] = K[((size_t)b * Sk + r) * ldk + h * D + c];
-        v[i] = V[((size_t)b * Sk + r) * ldv + h * D + c];
-    }
-    __syncthreads();
-    constexpr float NEG = -3.4028234663852886e38f;
-    for (int i = tid; i < Sq * Sk; i += 256) {
-        const int r = i / Sk, c = i % Sk;
-        float s = 0.f;
-        for (int d = 0; d < D; ++d) s += q[r * D + d] * k[c * D + d];
-        s *= scale;
-        if ((key_mask && key_mask[(size_t)b * Sk + c] == 0) || (causal && c > r)) s = fminf(s + NEG, NEG);
-        P[i] = s;
-    }
-    __syncthreads();
-    for (int r = tid; r < Sq; r += 256) {  // row softmax
-        float mx = -INFINITY, sum = 0.f;
-        for (int c = 0; c < Sk; ++c) mx = fmaxf(mx, P[r * Sk + c]);
-        for (int c = 0; c < Sk; ++c) { const float e = __expf(P[r * Sk + c] - mx); P[r * Sk + c] = e; sum += e; }
-        const float inv = 1.0f / sum;
-        for (int c = 0; c < Sk; ++c) P[r * Sk + c] *= inv;
-    }
-    __syncthreads();
-    for (int i = tid; i < Sk * D; i += 256) {  // dV = P^T dO
-        const int c = i / D, d = i % D;
-        float a = 0.f;
-        for (int r = 0; r < Sq; ++r) a += P[r * Sk + c] * g[r * D + d];
-        dV[((size_t)b * Sk + c) * ldv + h * D + d] = a;
-    }
-    for (int r = tid; r < Sq; r += 256) Dr[r] = 0.f;
-    __syncthreads();
-    // dP_ij = dO_i . V_j ; D_i = sum_j P_ij dP_ij
-    for (int i = tid; i < Sq * Sk; i += 256) {
-        const int r = i / Sk, c = i % Sk;
-        float a = 0.f;
-        for (int d = 0; d < D; ++d) a += g[r * D + d] * v[c * D + d];
-        atomicAdd(&Dr[r], P[i] * a);
-    }
-    __syncthreads();
-    for (int i = tid; i < Sq * Sk; i += 256) {
-        const int r = i / Sk, c = i % Sk;
-        float a = 0.f;
-        for (int d = 0; d < D; ++d) a += g[r * D + d] * v[c * D + d];
-        P[i] = P[i] * (a - Dr[r]) * scale;  // dS
-    }
-    __syncthreads();
-    for (int i = tid; i < Sq * D; i += 256) {  // dQ = dS K
-        const int r = i / D, d = i % D;
-        float a = 0.f;
-        for (int c = 0; c < Sk; ++c) a += P[r * Sk + c] * k[c * D + d];
-        dQ[((size_t)b * Sq + r) * ldq + h * D + d] = a;
-    }
-    for (int i = tid; i < Sk * D; i += 256) {  // dK = dS^T Q
-        const int c = i / D, d = i % D;
-        float a = 0.f;
-        for (int r = 0; r < Sq; ++r) a += P[r * Sk + c] * q[r * D + d];
-        dK[((size_t)b * Sk + c) * ldk + h * D + d] = a;
-    }
+// One head lives in LDS as fp32 (Sq, Sk <= 96, D <= 64); P is recomputed from Q and K, not saved by the forward.  The five
+// products are register-tiled fp32 FMA loops (16 x 16 threads, 4 x 4 or 4 x NJ outputs each) fed by 16-byte LDS reads: rows are
+// padded to D + 4 (and Sk + 4) floats, so the 16 rows a wave reads at once fall into distinct banks.  HBM traffic is the
+// operands once and the three gradients once; the work is 5 x 2 Sq Sk D FLOPs per head on the vector ALUs -- fp32 throughout,
+// because the gradient fixtures are checked at 1e-5-class tolerances (MFMA would need the three-product split of the forward).
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ void fma4(float (&acc)[4], float a, const float4& b) {
+    acc[0] += a * b.x; acc[1] += a * b.y; acc[2] += a * b.z; acc[3] += a * b.w;
+}
+__device__ __forceinline__ const float4& ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// C[m][n] = sum_r A[r][m] B[r][n] (m contiguous in A, n in B), m < Mv, n < Nv (both multiples of 4), stored as float4 rows
+template <class Store>
+__device__ __forceinline__ void mm_tn(const float* A, int lda, const float* B, int ldb, int Mv, int Nv, int R, int ty, int tx, Store store) {
+    for (int m0 = 0; m0 < Mv; m0 += 64)
+        for (int n0 = 0; n0 < Nv; n0 += 64) {
+            const int mo = min(m0 + ty * 4, Mv - 4), no = min(n0 + tx * 4, Nv - 4);
+            float acc[4][4] = {};
+            for (int r = 0; r < R; ++r) {
+                const float4 a = ld4(A + r * lda + mo), b = ld4(B + r * ldb + no);
+                fma4(acc[0], a.x, b); fma4(acc[1], a.y, b); fma4(acc[2], a.z, b); fma4(acc[3], a.w, b);
+            }
+            if (mo == m0 + ty * 4 && no == n0 + tx * 4)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) store(mo + i, no, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
+        }
 }
 
-extern "C" int didi_attention_backward(const float* Q, const float* K, const float* V, const float* dO, const int32_t* key_mask, int B,
-                                       int heads, int Sq, int Sk, int D, int ldq, int ldk, int ldv, int ldo, int causal, float scale,
-                                       float* dQ, float* dK, float* dV, void* stream) {
+template <int NJ>
+__global__ void __launch_bounds__(256) attention_backward_kernel(const float* Q, const float* K, const float* V, const float* dO,
+                                                                 const int32_t* key_mask, int Sq, int Sk, int D, int ldq, int ldk, int ldv,
+                                                                 int ldo, int causal, float scale, float* dQ, float* dK, float* dV) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int LD = D + 4, Sk4 = (Sk + 3) & ~3, LP = Sk4 + 4, L4 = LD / 4, D_4 = D / 4;
+    float* q = sm;            // [Sq][LD]
+    float* k = q + Sq * LD;   // [Sk][LD]
+    float* v = k + Sk * LD;   // [Sk][LD]
+    float* g = v + Sk * LD;   // dO [Sq][LD]
+    float* P = g + Sq * LD;   // [Sq][LP]: scores -> probabilities -> dS
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < Sq * L4; i += 256) {
+        const int r = i / L4, c = i % L4;
+        reinterpret_cast<float4*>(q)[i] = c < D_4 ? ld4(Q + ((size_t)b * Sq + r) * ldq + h * D + c * 4) : z4;
+        reinterpret_cast<float4*>(g)[i] = c < D_4 ? ld4(dO + ((size_t)b * Sq + r) * ldo + h * D + c * 4) : z4;
+    }
+    for (int i = tid; i < Sk * L4; i += 256) {
+        const int r = i / L4, c = i % L4;
+        reinterpret_cast<float4*>(k)[i] = c < D_4 ? ld4(K + ((size_t)b * Sk + r) * ldk + h * D + c * 4) : z4;
+        reinterpret_cast<float4*>(v)[i] = c < D_4 ? ld4(V + ((size_t)b * Sk + r) * ldv + h * D + c * 4) : z4;
+    }
+    for (int i = tid; i < Sq * (LP - Sk); i += 256) P[(i / (LP - Sk)) * LP + Sk + i % (LP - Sk)] = 0.f;  // padding columns stay zero
+    __syncthreads();
+    constexpr float NEG = -3.4028234663852886e38f;
+    // ---- scores: P[r][c] = scale q_r . k_c (+ masks); thread = rows ty + 16 i, columns tx + 16 j
+    for (int r0 = 0; r0 < Sq; r0 += 64) {
+        float acc[4][NJ] = {};
+        int ra[4], cb[NJ];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = min(r0 + ty + 16 * i, Sq - 1) * LD;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cb[j] = min(tx + 16 * j, Sk - 1) * LD;
+        for (int kk = 0; kk < D; kk += 4) {
+            float4 a[4], bb[NJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = ld4(q + ra[i] + kk);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bb[j] = ld4(k + cb[j] + kk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] += dot4(a[i], bb[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int r = r0 + ty + 16 * i, c = tx + 16 * j;
+                if (r < Sq && c < Sk) {
+                    float sc = acc[i][j] * scale;
+                    if ((key_mask && key_mask[(size_t)b * Sk + c] == 0) || (causal && c > r)) sc = fminf(sc + NEG, NEG);
+                    P[r * LP + c] = sc;
+                }
+            }
+    }
+    __syncthreads();
+    // ---- row softmax: four lanes per row
+    for (int r = tid >> 2; r < Sq; r += 64) {
+        float* row = P + r * LP;
+        float mx = -INFINITY, sum = 0.f;
+        for (int c = tid & 3; c < Sk; c += 4) mx = fmaxf(mx, row[c]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        for (int c = tid & 3; c < Sk; c += 4) { const float e = __expf(row[c] - mx); row[c] = e; sum += e; }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        const float inv = 1.0f / sum;
+        for (int c = tid & 3; c < Sk; c += 4) row[c] *= inv;
+    }
+    __syncthreads();
+    // ---- dV = P^T dO
+    mm_tn(P, LP, g, LD, Sk4, D, Sq, ty, tx, [&](int m, int n, const float4& val) {
+        if (m < Sk) *reinterpret_cast<float4*>(dV + ((size_t)b * Sk + m) * ldv + h * D + n) = val;
+    });
+    __syncthreads();
+    // ---- dP = dO V^T in registers; D_i = sum_c P dP over the 16 lanes sharing a row; dS = P (dP - D) scale, in place of P
+    for (int r0 = 0; r0 < Sq; r0 += 64) {
+        float acc[4][NJ] = {};
+        int ra[4], cb[NJ];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = min(r0 + ty + 16 * i, Sq - 1) * LD;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cb[j] = min(tx + 16 * j, Sk - 1) * LD;
+        for (int kk = 0; kk < D; kk += 4) {
+            float4 a[4], bb[NJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = ld4(g + ra[i] + kk);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bb[j] = ld4(v + cb[j] + kk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] += dot4(a[i], bb[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = min(r0 + ty + 16 * i, Sq - 1);
+            float pv[NJ], dr = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = tx + 16 * j;
+                pv[j] = c < Sk ? P[r * LP + c] : 0.f;
+                dr += pv[j] * acc[i][j];
+            }
+            dr += __shfl_xor(dr, 1, 64);
+            dr += __shfl_xor(dr, 2, 64);
+            dr += __shfl_xor(dr, 4, 64);
+            dr += __shfl_xor(dr, 8, 64);
+            if (r0 + ty + 16 * i < Sq)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int c = tx + 16 * j;
+                    if (c < Sk) P[r * LP + c] = pv[j] * (acc[i][j] - dr) * scale;
+                }
+        }
+    }
+    __syncthreads();
+    // ---- dQ = dS K: rows ty + 16 i, columns 4 tx .. 4 tx + 3
+    for (int r0 = 0; r0 < Sq; r0 += 64) {
+        const int no = min(tx * 4, D - 4);
+        float acc[4][4] = {};
+        int ra[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = min(r0 + ty + 16 * i, Sq - 1) * LP;
+        for (int kk = 0; kk < Sk4; kk += 4) {
+            float4 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = ld4(P + ra[i] + kk);
+            const float4 b0 = ld4(k + min(kk, Sk - 1) * LD + no), b1 = ld4(k + min(kk + 1, Sk - 1) * LD + no),
+                         b2 = ld4(k + min(kk + 2, Sk - 1) * LD + no), b3 = ld4(k + min(kk + 3, Sk - 1) * LD + no);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fma4(acc[i], a[i].x, b0); fma4(acc[i], a[i].y, b1); fma4(acc[i], a[i].z, b2); fma4(acc[i], a[i].w, b3); }
+        }
+        if (no == tx * 4)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + ty + 16 * i;
+                if (r < Sq) *reinterpret_cast<float4*>(dQ + ((size_t)b * Sq + r) * ldq + h * D + no) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+            }
+    }
+    // ---- dK = dS^T Q
+    mm_tn(P, LP, q, LD, Sk4, D, Sq, ty, tx, [&](int m, int n, const float4& val) {
+        if (m < Sk) *reinterpret_cast<float4*>(dK + ((size_t)b * Sk + m) * ldk + h * D + n) = val;
+    });
+}
+
+extern "C" int didi_attention_backward(const float* Q, const float* K, const float* V, const float* dO, const int32_t* key_mask, int B, int heads,
+                                       int Sq, int Sk, int D, int ldq, int ldk, int ldv, int ldo, int causal, float scale, float* dQ, float* dK,
+                                       float* dV, void* stream) {
     DIDI_CHECK_ARG(Q && K && V && dO && dQ && dK && dV && B >= 0 && heads > 0 && Sq > 0 && Sk > 0 && D > 0);
-    if (Sq > 96 || Sk > 96 || D > 64) return DIDI_ERR_UNSUPPORTED;
+    if (Sq > 96 || Sk > 96 || D > 64 || D % 4 != 0) return DIDI_ERR_UNSUPPORTED;
     if (causal && Sq != Sk) return DIDI_ERR_BAD_ARG;
+    // 16-byte loads and stores of head slices: leading dimensions in multiples of 4 floats, bases 16-byte aligned
+    DIDI_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && ldq >= heads * D && ldk >= heads * D && ldv >= heads * D &&
+                   ldo >= heads * D);
+    for (const void* ptr : {(const void*)Q, (const void*)K, (const void*)V, (const void*)dO, (const void*)dQ, (const void*)dK, (const void*)dV})
+        DIDI_CHECK_ARG(reinterpret_cast<uintptr_t>(ptr) % 16 == 0);
     if (B == 0) return DIDI_OK;
-    const size_t lds = sizeof(float) * ((size_t)2 * Sq * D + 2 * Sk * D + (size_t)Sq * Sk + Sq);
+    const int LD = D + 4, LP = ((Sk + 3) & ~3) + 4;
+    const size_t lds = sizeof(float) * ((size_t)2 * Sq * LD + (size_t)2 * Sk * LD + (size_t)Sq * LP);
+    if (lds > 160 * 1024 - 256) return DIDI_ERR_UNSUPPORTED;
     static std::mutex mu;
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_backward_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_backward_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
             return DIDI_ERR_LAUNCH;
     }
-    attention_backward_kernel<<<dim3(heads, B), 256, lds, as_stream(stream)>>>(Q, K, V, dO, key_mask, heads, Sq, Sk, D, ldq, ldk, ldv, ldo, causal,
-                                                                             scale > 0.f ? scale : 1.0f / sqrtf((float)D), dQ, dK, dV);
+    const float sc = scale > 0.f ? scale : 1.0f / sqrtf((float)D);
+    if (Sk <= 64)
+        attention_backward_kernel<4><<<dim3(heads, B), 256, lds, as_stream(stream)>>>(Q, K, V, dO, key_mask, Sq, Sk, D, ldq, ldk, ldv, ldo, causal, sc, dQ, dK, dV);
+    else
+        attention_backward_kernel<6><<<dim3(heads, B), 256, lds, as_stream(stream)>>>(Q, K, V, dO, key_mask, Sq, Sk, D, ldq, ldk, ldv, ldo, causal, sc, dQ, dK, dV);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

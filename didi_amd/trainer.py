@@ -384,18 +384,21 @@ class DiDiTrainer:
         self.refresh_planes()
         return norm
 
-    def training_step(self, raw_context, target, world=None, **kw):
-        """forward + backward + (``world`` = a torch.distributed group or True: bucketed gradient all-reduce with the five logged
-        scalars folded into the last bucket, src/training.py:37 + model.py:241-242) + optimiser step -> the five scalars."""
+    def training_step(self, raw_context, target, world=1, **kw):
+        """forward + backward + (``world`` > 1: bucketed gradient all-reduce over the default process group with the five logged
+        scalars folded into the last bucket, src/training.py:37 + model.py:241-242) + clip + AdamW -> the step's dict with
+        ``metrics`` (fp32 [5]: mse, ce, t_T, loss, ce_hat, averaged over ranks) and ``grad_norm``."""
         from . import dist as ddist
         from .training import metric_message
 
         out = self.forward_backward(raw_context, target, **kw)
         metrics = metric_message(out)
-        if world is not None and world is not False:
+        if world > 1:
             names = list(self.params)
-            grads, metrics = ddist.allreduce_gradients([out["grads"][k] for k in names], None if world is True else world, metrics)
-            out["grads"] = dict(zip(names, grads))
+            grads = [out["grads"][k] for k in names]
+            for g_ in grads:
+                assert g_.is_contiguous()
+            metrics = ddist.allreduce_gradients(grads, world, metrics)  # in place
         out["grad_norm"] = self.optimizer_step(out["grads"])
         out["metrics"] = metrics
         return out

@@ -1203,7 +1203,10 @@ extern "C" int didi_gemm(const didi_gemm_args* a, void* stream) {
 // bias, activation, residual and, for the output projections, LayerNorm -- so the separate LayerNorm pass goes away too.
 static int small_splits(int M, int N, int K, int precision) {
     const int max_m = didi_opt(DIDI_OPT_SMALL_MAX_M);  // tuning knob
-    if (M <= 0 || M >= max_m || N % 4 != 0 || N > 3072) return 0;
+    if (M <= 0 || N % 4 != 0 || N > 3072) return 0;
+    // weight-gradient shapes (dW = dC^T A: a few thousand rows, K = the batch's B S rows) have the same problem at any M: a
+    // few dozen output tiles, each walking a very long K.  The sampler's shapes (K <= 5120) never take this branch.
+    if (M >= max_m && !(K >= 8192 && cdiv(M, BM) * cdiv(N, BN) < 256)) return 0;
     const int unit = 128;  // K columns per split are a multiple of this (two one-product K-tiles, four bf16x3 ones)
     if (K % unit != 0 || K < 2 * unit) return 0;
     if (precision != DIDI_PREC_BF16 && precision != DIDI_PREC_FP16 && precision != DIDI_PREC_BF16X3 && precision != DIDI_PREC_FP16X2 && precision != DIDI_PREC_FP16X3) return 0;

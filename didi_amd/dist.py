@@ -149,3 +149,21 @@ def allreduce_gradients(grads, world, metrics=None, bucket_bytes=64 << 20, avera
         if tail:
             out_metrics = flat[off: off + metrics.numel()].clone()
     return out_metrics
+
+
+def allreduce_flat(flat, world, bucket_bytes=64 << 20, tail=0):
+    """Mean over ranks of ONE flat fp32 buffer, in place: the trainer keeps its gradients contiguous (didi_amd/trainer.py), so the
+    buckets are slices -- no packing copies -- and each is one ``all_reduce``.  The last ``tail`` floats (the five logged scalars
+    of ``log_dict(sync_dist=True)``, src/diffusion/model.py:241-242) always travel with the last bucket, never alone."""
+    if world <= 1:
+        return flat
+    assert flat.dtype == torch.float32 and flat.is_contiguous() and flat.dim() == 1
+    per = max(1, bucket_bytes // 4)
+    n = flat.numel()
+    start = 0
+    while start < n:
+        end = n if n - start <= per + tail else start + per
+        dist.all_reduce(flat[start:end], op=dist.ReduceOp.SUM)
+        start = end
+    flat /= world
+    return flat

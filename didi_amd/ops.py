@@ -328,7 +328,9 @@ def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True):
     dA = gemm(dc_hi, dc_lo, wt_hi, wt_lo, precision=precision, out_f32=True, out_planes=False)[2] if need_dA else None
     dct_hi, dct_lo = transpose_split(dC, dtype=pd)       # [N, M8]
     at_hi, at_lo = transpose_split(A, dtype=pd)          # [K, M8]
-    _, _, dW = gemm(dct_hi, dct_lo, at_hi, at_lo, precision=precision, out_f32=True, out_planes=False)
+    # wgrad: few output tiles, K = the batch's rows -> the split-K form wherever it applies
+    use_small = lib.didi_gemm_small_workspace_bytes(N, K, dct_hi.shape[1], _prec(precision)) > 0
+    _, _, dW = gemm(dct_hi, dct_lo, at_hi, at_lo, precision=precision, out_f32=True, out_planes=False, small=() if use_small else None)
     return dA, dW, (colsum(dC) if bias else None)
 
 

@@ -92,11 +92,24 @@ class DiDiTrainer:
             self._layer_names.append(ln)
             for v in ln.values():
                 names += [v + ".weight", v + ".bias"]
+        # one flat fp32 buffer for all trainable parameters (and one each for AdamW's moments): the parameter dict holds views,
+        # so the optimiser is ONE launch over the buffer and the gradient all-reduce walks contiguous buckets of its twin
+        sizes = [state_dict[n].numel() for n in names]
+        pad = lambda n_: (n_ + 3) // 4 * 4  # noqa: E731  (every view 16-byte aligned)
+        self._offsets, off = {}, 0
+        for n, sz in zip(names, sizes):
+            self._offsets[n] = off
+            off += pad(sz)
+        self._n_flat = off
+        self._flat_p = torch.zeros(off, dtype=torch.float32, device=self.device)
         for n in names:
-            P[n] = f(n)
+            src = f(n)
+            P[n] = self._flat_p[self._offsets[n]: self._offsets[n] + src.numel()].view(src.shape)
+            P[n].copy_(src)
         self.params = P
-        self.m = {k: torch.zeros_like(v) for k, v in P.items()}
-        self.v = {k: torch.zeros_like(v) for k, v in P.items()}
+        self._flat_m, self._flat_v = torch.zeros_like(self._flat_p), torch.zeros_like(self._flat_p)
+        view = lambda flat: {n: flat[self._offsets[n]: self._offsets[n] + P[n].numel()].view(P[n].shape) for n in names}  # noqa: E731
+        self.m, self.v = view(self._flat_m), view(self._flat_v)
         self.step_count = 0
         self._build_linears()
 
@@ -365,22 +378,46 @@ class DiDiTrainer:
             return lr_linear(step, o["lr"], o["min_lr"], o["warmup_steps"], o["decay_range"])
         return lr_rsqrt_with_warmup(step, o["lr"], o["min_lr"], o["warmup_steps"])
 
+    METRIC_SLOTS = 8  # tail of the flat gradient buffer: the five logged scalars ride in the last all-reduce bucket
+
+    @torch.no_grad()
+    def flatten_gradients(self, grads, metrics=None):
+        """{name: fp32} -> one flat buffer laid out like the parameters (+ METRIC_SLOTS tail floats holding ``metrics``)."""
+        flat = torch.zeros(self._n_flat + self.METRIC_SLOTS, dtype=torch.float32, device=self.device)
+        dst, src = [], []
+        for n, off in self._offsets.items():
+            g_ = grads[n]
+            assert g_.shape == self.params[n].shape, n
+            dst.append(flat[off: off + g_.numel()].view(g_.shape))
+            src.append(g_)
+        torch._foreach_copy_(dst, src)  # memory plumbing: a handful of batched copy launches instead of one per tensor
+        if metrics is not None:
+            flat[self._n_flat: self._n_flat + metrics.numel()] = metrics
+        return flat
+
+    def allreduce_flat(self, flat, world, bucket_bytes=64 << 20):
+        """Mean over ranks of the flat gradient buffer (metric tail included), in place: didi_amd.dist.allreduce_flat."""
+        from . import dist as ddist
+
+        return ddist.allreduce_flat(flat, world, bucket_bytes=bucket_bytes, tail=self.METRIC_SLOTS)
+
     @torch.no_grad()
     def optimizer_step(self, grads):
         """Clip the global gradient norm to ``gradient_clip_val`` (Lightning's clip_grad_norm_: coefficient
         min(1, clip / (norm + 1e-6))), then AdamW(lr = 1 x lambda(step), betas (0.9, 0.999), eps 1e-8) on every parameter.
-        LambdaLR semantics: the k-th optimizer.step() (k = 1, 2, ...) runs with lambda(k - 1).  -> gradient norm (device)."""
+        LambdaLR semantics: the k-th optimizer.step() (k = 1, 2, ...) runs with lambda(k - 1).
+        ``grads``: {name: fp32} or the flat buffer of ``flatten_gradients``.  -> gradient norm (device)."""
+        flat = grads if torch.is_tensor(grads) else self.flatten_gradients(grads)
+        g = flat[: self._n_flat]
         lr = self.lr_at(self.step_count)
         self.step_count += 1
         total = torch.zeros(1, dtype=torch.float32, device=self.device)
-        for k in self.params:
-            ops.sumsq_accumulate(grads[k], total)
+        ops.sumsq_accumulate(g, total)
         norm = total.sqrt()
         gscale = None
         if self.clip is not None:
             gscale = torch.clamp(float(self.clip) / (norm + 1e-6), max=1.0)
-        for k, p_ in self.params.items():
-            ops.adamw_step(p_, grads[k], self.m[k], self.v[k], lr, 0.9, 0.999, 1e-8, self.opt["weight_decay"], self.step_count, gscale)
+        ops.adamw_step(self._flat_p, g, self._flat_m, self._flat_v, lr, 0.9, 0.999, 1e-8, self.opt["weight_decay"], self.step_count, gscale)
         self.refresh_planes()
         return norm
 
@@ -388,17 +425,11 @@ class DiDiTrainer:
         """forward + backward + (``world`` > 1: bucketed gradient all-reduce over the default process group with the five logged
         scalars folded into the last bucket, src/training.py:37 + model.py:241-242) + clip + AdamW -> the step's dict with
         ``metrics`` (fp32 [5]: mse, ce, t_T, loss, ce_hat, averaged over ranks) and ``grad_norm``."""
-        from . import dist as ddist
         from .training import metric_message
 
         out = self.forward_backward(raw_context, target, **kw)
-        metrics = metric_message(out)
-        if world > 1:
-            names = list(self.params)
-            grads = [out["grads"][k] for k in names]
-            for g_ in grads:
-                assert g_.is_contiguous()
-            metrics = ddist.allreduce_gradients(grads, world, metrics)  # in place
-        out["grad_norm"] = self.optimizer_step(out["grads"])
-        out["metrics"] = metrics
+        flat = self.flatten_gradients(out["grads"], metric_message(out))
+        self.allreduce_flat(flat, world)
+        out["grad_norm"] = self.optimizer_step(flat)
+        out["metrics"] = flat[self._n_flat: self._n_flat + 5].clone()
         return out

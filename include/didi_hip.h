@@ -236,7 +236,9 @@ int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const float* beta,
  * optional LayerNorm over the N output columns: gamma/beta non-NULL, as didi_gemm_ln), organised for latency: K is split
  * over workgroups, the partial sums go through `workspace` (didi_gemm_small_workspace_bytes(M, N, K, precision) bytes,
  * 16-byte aligned; 0 = this form does not apply, use didi_gemm), and one row kernel applies bias, activation,
- * residual, LayerNorm and writes the outputs (ldc == N).  N <= 3072, N % 4 == 0, K % 128 == 0. */
+ * residual, LayerNorm and writes the outputs (ldc == N).  N <= 3072, N % 4 == 0, K % 128 == 0.
+ * Also taken, at any M, by weight-gradient shapes of the training step (K >= 8192 with fewer than 256 output tiles):
+ * dW = dC^T A has a few dozen 128 x 128 tiles, each walking K = B S rows. */
 size_t didi_gemm_small_workspace_bytes(int M, int N, int K, int precision);
 int didi_gemm_small(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, void* workspace, void* stream);
 

@@ -155,3 +155,38 @@ def test_gradient_allreduce_world2_gloo_one_bucket_and_many():
     than a tensor (every tensor its own bucket) give the same averages on both ranks."""
     assert _run(_grad_worker, (64 << 20,), 2) == [(0, True, True), (1, True, True)]
     assert _run(_grad_worker, (64,), 2) == [(0, True, True), (1, True, True)]
+
+
+def _flat_worker(rank, world, port, bucket_bytes, q):
+    from didi_amd.dist import allreduce_flat
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, tail = 1000, 8
+    mine = torch.randn(n + tail, generator=torch.Generator().manual_seed(7 + rank))
+    want = sum(torch.randn(n + tail, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)) / world
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, **kw):
+        calls.append(t.numel())
+        return real(t, **kw)
+
+    dist.all_reduce = counting
+    try:
+        got = allreduce_flat(mine, world, bucket_bytes=bucket_bytes, tail=tail)
+    finally:
+        dist.all_reduce = real
+    per = max(1, bucket_bytes // 4)
+    ok = got.data_ptr() == mine.data_ptr() and torch.allclose(got, want, atol=1e-6)
+    # buckets tile the buffer exactly, and the metric tail never travels alone
+    ok = ok and sum(calls) == n + tail and calls[-1] > tail and all(c == per for c in calls[:-1])
+    q.put((rank, bool(ok), True))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world2_gloo():
+    """The trainer's contiguous gradient buffer: buckets are slices (no packing), the metric tail rides in the last one."""
+    assert _run(_flat_worker, (64 << 20,), 2) == [(0, True, True), (1, True, True)]
+    assert _run(_flat_worker, (400,), 2) == [(0, True, True), (1, True, True)]    # 100-float buckets: 10 of them, last = 100 + 8
+    assert _run(_flat_worker, (4 * 252,), 2) == [(0, True, True), (1, True, True)]  # remainder 244 + 8 <= 252 + 8: folded into one

@@ -226,10 +226,48 @@ def main_training(args):
                      "note": "algorithmic GEMM FLOPs of one step (3 x forward) / the whole step time; the backward's attention and elementwise "
                              "kernels are correctness-level this round (DESIGN.md section 8)"},
     }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_training(cfg, sd, batches[0], tr)
+        res["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def cpu_baseline_training(cfg, sd, batch, tr, slice_dialogs=64, passes=3):
+    """The CPU oracle's training step (fp32 torch eager forward + autograd backward, oracle/training.py) on the first
+    `slice_dialogs` dialogs of the first batch (M = 4096 rows: the CPU GEMMs are compute-bound there), one warm-up + `passes` timed
+    passes, the fastest kept; the optimiser step is NOT timed (both choices favour the CPU)."""
+    from golden_util import config_to_oracle_config
+    from oracle.training import training_step_with_grads
+
+    from didi_amd.synthetic import RawContext
+
+    threads = torch.get_num_threads()
+    cpu_model, phys = host_cpu()
+    sd = dict(sd)
+    sd.setdefault("sigmas", tr.sigmas.detach().cpu())
+    sd.setdefault("std_0", torch.tensor(tr.std_0))
+    if "classifier.weight" not in sd:
+        sd["classifier.weight"] = sd["emb.weight"]
+    n = slice_dialogs
+    ctx = RawContext(batch[0].input_ids[:n].cpu(), batch[0].attention_mask[:n].cpu())
+    tgt = RawContext(batch[1].input_ids[:n].cpu(), batch[1].attention_mask[:n].cpu())
+    S, H = tgt.input_ids.shape[1], cfg.dec_dim
+    g = torch.Generator().manual_seed(3)
+    draws = [torch.randn(n, S, H, generator=g), torch.randn(n, S, H, generator=g)]
+    t = torch.randint(1, cfg.diffusion_steps + 1, (n, 1), generator=g)
+    ocfg = config_to_oracle_config(cfg)
+    times = []
+    for _ in range(1 + passes):
+        t0 = time.perf_counter()
+        training_step_with_grads(sd, ocfg, ctx, tgt, draws, t)
+        times.append(time.perf_counter() - t0)
+    return {"value": round(n / min(times[1:]), 3), "unit": "dialogs/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
+            "physical_cores_visible": phys,
+            "sample": (f"CPU oracle training step (fp32 torch eager forward + autograd backward, no optimiser step) on a {n}-dialog slice of the "
+                       f"batch, {threads} threads on '{cpu_model}': warm-up {times[0]:.2f}s, timed passes {', '.join(f'{x:.2f}s' for x in times[1:])} (fastest kept)")}
 
 
 def main():

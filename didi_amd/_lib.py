@@ -176,6 +176,9 @@ SYMBOLS = [
     ("didi_attention_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
+    ("didi_attention_train_forward", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("didi_attention_train_backward", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("didi_dropout_add", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     ("didi_adamw_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     ("didi_sumsq_accumulate", C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -454,32 +454,37 @@ __device__ __forceinline__ void mm_tn(const float* A, int lda, const float* B, i
         }
 }
 
-template <int NJ>
-__global__ void __launch_bounds__(256) attention_backward_kernel(const float* Q, const float* K, const float* V, const float* dO,
-                                                                 const int32_t* key_mask, int Sq, int Sk, int D, int ldq, int ldk, int ldv,
-                                                                 int ldo, int causal, float scale, float* dQ, float* dK, float* dV) {
+// The training forward runs the same fp32 arrangement (FWD: Q K V in LDS, O = P V out), so that attention-probability dropout
+// (HF:bert:129, attention_probs_dropout_prob) is ONE mask definition shared by forward and backward: element (b, h, i, j) keeps
+// its probability iff word (j & 3) of Philox4x32-10(counter = offset + (((b heads + h) Sq + i) Sk4 + j) / 4, key = seed) is
+// >= p 2^32, Sk4 = Sk rounded up to 4.  In LDS a dropped probability is stored NEGATED (probabilities are >= 0, -0.0 included):
+// products that want the dropped matrix clamp at zero, the softmax backward takes |P|; kept entries are scaled by 1 / (1 - p).
+template <int NJ, bool BWD>
+__global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_args p) {
     extern __shared__ float sm[];
+    const int Sq = p.Sq, Sk = p.Sk, D = p.D;
     const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int LD = D + 4, Sk4 = (Sk + 3) & ~3, LP = Sk4 + 4, L4 = LD / 4, D_4 = D / 4;
-    float* q = sm;            // [Sq][LD]
-    float* k = q + Sq * LD;   // [Sk][LD]
-    float* v = k + Sk * LD;   // [Sk][LD]
-    float* g = v + Sk * LD;   // dO [Sq][LD]
-    float* P = g + Sq * LD;   // [Sq][LP]: scores -> probabilities -> dS
+    float* q = sm;                            // [Sq][LD]
+    float* k = q + Sq * LD;                   // [Sk][LD]
+    float* v = k + Sk * LD;                   // [Sk][LD]
+    float* g = v + Sk * LD;                   // dO [Sq][LD] (BWD only)
+    float* P = BWD ? g + Sq * LD : g;         // [Sq][LP]: scores -> probabilities (sign = dropout) -> dS
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < Sq * L4; i += 256) {
         const int r = i / L4, c = i % L4;
-        reinterpret_cast<float4*>(q)[i] = c < D_4 ? ld4(Q + ((size_t)b * Sq + r) * ldq + h * D + c * 4) : z4;
-        reinterpret_cast<float4*>(g)[i] = c < D_4 ? ld4(dO + ((size_t)b * Sq + r) * ldo + h * D + c * 4) : z4;
+        reinterpret_cast<float4*>(q)[i] = c < D_4 ? ld4(p.Q + ((size_t)b * Sq + r) * p.ldq + h * D + c * 4) : z4;
+        if (BWD) reinterpret_cast<float4*>(g)[i] = c < D_4 ? ld4(p.dO + ((size_t)b * Sq + r) * p.ldo + h * D + c * 4) : z4;
     }
     for (int i = tid; i < Sk * L4; i += 256) {
         const int r = i / L4, c = i % L4;
-        reinterpret_cast<float4*>(k)[i] = c < D_4 ? ld4(K + ((size_t)b * Sk + r) * ldk + h * D + c * 4) : z4;
-        reinterpret_cast<float4*>(v)[i] = c < D_4 ? ld4(V + ((size_t)b * Sk + r) * ldv + h * D + c * 4) : z4;
+        reinterpret_cast<float4*>(k)[i] = c < D_4 ? ld4(p.K + ((size_t)b * Sk + r) * p.ldk + h * D + c * 4) : z4;
+        reinterpret_cast<float4*>(v)[i] = c < D_4 ? ld4(p.V + ((size_t)b * Sk + r) * p.ldv + h * D + c * 4) : z4;
     }
     for (int i = tid; i < Sq * (LP - Sk); i += 256) P[(i / (LP - Sk)) * LP + Sk + i % (LP - Sk)] = 0.f;  // padding columns stay zero
     __syncthreads();
     constexpr float NEG = -3.4028234663852886e38f;
+    const float scale = p.scale;
     // ---- scores: P[r][c] = scale q_r . k_c (+ masks); thread = rows ty + 16 i, columns tx + 16 j
     for (int r0 = 0; r0 < Sq; r0 += 64) {
         float acc[4][NJ] = {};
@@ -506,7 +511,7 @@ __global__ void __launch_bounds__(256) attention_backward_kernel(const float* Q,
                 const int r = r0 + ty + 16 * i, c = tx + 16 * j;
                 if (r < Sq && c < Sk) {
                     float sc = acc[i][j] * scale;
-                    if ((key_mask && key_mask[(size_t)b * Sk + c] == 0) || (causal && c > r)) sc = fminf(sc + NEG, NEG);
+                    if ((p.key_mask && p.key_mask[(size_t)b * Sk + c] == 0) || (p.causal && c > r)) sc = fminf(sc + NEG, NEG);
                     P[r * LP + c] = sc;
                 }
             }
@@ -526,109 +531,231 @@ __global__ void __launch_bounds__(256) attention_backward_kernel(const float* Q,
         for (int c = tid & 3; c < Sk; c += 4) row[c] *= inv;
     }
     __syncthreads();
-    // ---- dV = P^T dO
-    mm_tn(P, LP, g, LD, Sk4, D, Sq, ty, tx, [&](int m, int n, const float4& val) {
-        if (m < Sk) *reinterpret_cast<float4*>(dV + ((size_t)b * Sk + m) * ldv + h * D + n) = val;
-    });
-    __syncthreads();
-    // ---- dP = dO V^T in registers; D_i = sum_c P dP over the 16 lanes sharing a row; dS = P (dP - D) scale, in place of P
-    for (int r0 = 0; r0 < Sq; r0 += 64) {
-        float acc[4][NJ] = {};
-        int ra[4], cb[NJ];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = min(r0 + ty + 16 * i, Sq - 1) * LD;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) cb[j] = min(tx + 16 * j, Sk - 1) * LD;
-        for (int kk = 0; kk < D; kk += 4) {
-            float4 a[4], bb[NJ];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = ld4(g + ra[i] + kk);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bb[j] = ld4(v + cb[j] + kk);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] += dot4(a[i], bb[j]);
+    // ---- dropout: negate the dropped probabilities
+    const bool drop = p.drop_p > 0.f;
+    const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+    if (drop) {
+        const uint32_t thr = (uint32_t)fminf(p.drop_p * 4294967296.0f, 4294967040.0f);
+        const int G4 = Sk4 / 4;
+        for (int i = tid; i < Sq * G4; i += 256) {
+            const int r = i / G4, c4 = i % G4;
+            uint32_t w[4];
+            philox4x32_10(p.offset + (((uint64_t)b * gridDim.x + h) * Sq + r) * G4 + c4, p.seed, w);
+            float4* cell = reinterpret_cast<float4*>(P + r * LP + c4 * 4);
+            float4 t = *cell;
+            if (w[0] < thr) t.x = -t.x;
+            if (w[1] < thr) t.y = -t.y;
+            if (w[2] < thr) t.z = -t.z;
+            if (w[3] < thr) t.w = -t.w;
+            *cell = t;
         }
+        __syncthreads();
+    }
+    if constexpr (!BWD) {
+        // ---- O = dropout(P) V: rows ty + 16 i, columns 4 tx .. 4 tx + 3
+        for (int r0 = 0; r0 < Sq; r0 += 64) {
+            const int no = min(tx * 4, D - 4);
+            float acc[4][4] = {};
+            int ra[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = min(r0 + ty + 16 * i, Sq - 1);
-            float pv[NJ], dr = 0.f;
+            for (int i = 0; i < 4; ++i) ra[i] = min(r0 + ty + 16 * i, Sq - 1) * LP;
+            for (int kk = 0; kk < Sk4; kk += 4) {
+                float4 a[4];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int c = tx + 16 * j;
-                pv[j] = c < Sk ? P[r * LP + c] : 0.f;
-                dr += pv[j] * acc[i][j];
+                for (int i = 0; i < 4; ++i) {
+                    a[i] = ld4(P + ra[i] + kk);
+                    a[i].x = fmaxf(a[i].x, 0.f); a[i].y = fmaxf(a[i].y, 0.f); a[i].z = fmaxf(a[i].z, 0.f); a[i].w = fmaxf(a[i].w, 0.f);
+                }
+                const float4 b0 = ld4(v + min(kk, Sk - 1) * LD + no), b1 = ld4(v + min(kk + 1, Sk - 1) * LD + no),
+                             b2 = ld4(v + min(kk + 2, Sk - 1) * LD + no), b3 = ld4(v + min(kk + 3, Sk - 1) * LD + no);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { fma4(acc[i], a[i].x, b0); fma4(acc[i], a[i].y, b1); fma4(acc[i], a[i].z, b2); fma4(acc[i], a[i].w, b3); }
             }
-            dr += __shfl_xor(dr, 1, 64);
-            dr += __shfl_xor(dr, 2, 64);
-            dr += __shfl_xor(dr, 4, 64);
-            dr += __shfl_xor(dr, 8, 64);
-            if (r0 + ty + 16 * i < Sq)
+            if (no == tx * 4)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = r0 + ty + 16 * i;
+                    if (r < Sq)
+                        *reinterpret_cast<float4*>(p.O + ((size_t)b * Sq + r) * p.ldo + h * D + no) =
+                            make_float4(acc[i][0] * inv_keep, acc[i][1] * inv_keep, acc[i][2] * inv_keep, acc[i][3] * inv_keep);
+                }
+        }
+        return;
+    } else {
+        // ---- dV = dropout(P)^T dO
+        for (int m0 = 0; m0 < Sk4; m0 += 64) {
+            const int mo = min(m0 + ty * 4, Sk4 - 4), no = min(tx * 4, D - 4);
+            float acc[4][4] = {};
+            for (int r = 0; r < Sq; ++r) {
+                float4 a = ld4(P + r * LP + mo);
+                const float4 bb = ld4(g + r * LD + no);
+                a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+                fma4(acc[0], a.x, bb); fma4(acc[1], a.y, bb); fma4(acc[2], a.z, bb); fma4(acc[3], a.w, bb);
+            }
+            if (mo == m0 + ty * 4 && no == tx * 4)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (mo + i < Sk)
+                        *reinterpret_cast<float4*>(p.dV + ((size_t)b * Sk + mo + i) * p.ldv + h * D + no) =
+                            make_float4(acc[i][0] * inv_keep, acc[i][1] * inv_keep, acc[i][2] * inv_keep, acc[i][3] * inv_keep);
+        }
+        __syncthreads();
+        // ---- dP = (dO V^T) o mask / keep in registers; D_i = sum_c |P| dP over the 16 lanes sharing a row; dS = |P| (dP - D) scale
+        for (int r0 = 0; r0 < Sq; r0 += 64) {
+            float acc[4][NJ] = {};
+            int ra[4], cb[NJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = min(r0 + ty + 16 * i, Sq - 1) * LD;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) cb[j] = min(tx + 16 * j, Sk - 1) * LD;
+            for (int kk = 0; kk < D; kk += 4) {
+                float4 a[4], bb[NJ];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = ld4(g + ra[i] + kk);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bb[j] = ld4(v + cb[j] + kk);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] += dot4(a[i], bb[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = min(r0 + ty + 16 * i, Sq - 1);
+                float pv[NJ], dr = 0.f;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int c = tx + 16 * j;
-                    if (c < Sk) P[r * LP + c] = pv[j] * (acc[i][j] - dr) * scale;
+                    const float sp = c < Sk ? P[r * LP + c] : 0.f;
+                    pv[j] = fabsf(sp);
+                    acc[i][j] = __builtin_signbitf(sp) ? 0.f : acc[i][j] * inv_keep;
+                    dr += pv[j] * acc[i][j];
+                }
+                dr += __shfl_xor(dr, 1, 64);
+                dr += __shfl_xor(dr, 2, 64);
+                dr += __shfl_xor(dr, 4, 64);
+                dr += __shfl_xor(dr, 8, 64);
+                if (r0 + ty + 16 * i < Sq)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int c = tx + 16 * j;
+                        if (c < Sk) P[r * LP + c] = pv[j] * (acc[i][j] - dr) * scale;
+                    }
+            }
+        }
+        __syncthreads();
+        // ---- dQ = dS K: rows ty + 16 i, columns 4 tx .. 4 tx + 3
+        for (int r0 = 0; r0 < Sq; r0 += 64) {
+            const int no = min(tx * 4, D - 4);
+            float acc[4][4] = {};
+            int ra[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = min(r0 + ty + 16 * i, Sq - 1) * LP;
+            for (int kk = 0; kk < Sk4; kk += 4) {
+                float4 a[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = ld4(P + ra[i] + kk);
+                const float4 b0 = ld4(k + min(kk, Sk - 1) * LD + no), b1 = ld4(k + min(kk + 1, Sk - 1) * LD + no),
+                             b2 = ld4(k + min(kk + 2, Sk - 1) * LD + no), b3 = ld4(k + min(kk + 3, Sk - 1) * LD + no);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { fma4(acc[i], a[i].x, b0); fma4(acc[i], a[i].y, b1); fma4(acc[i], a[i].z, b2); fma4(acc[i], a[i].w, b3); }
+            }
+            if (no == tx * 4)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = r0 + ty + 16 * i;
+                    if (r < Sq)
+                        *reinterpret_cast<float4*>(p.dQ + ((size_t)b * Sq + r) * p.ldq + h * D + no) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
                 }
         }
+        // ---- dK = dS^T Q
+        float* dK = p.dK;
+        const int ldk = p.ldk;
+        mm_tn(P, LP, q, LD, Sk4, D, Sq, ty, tx, [&](int m, int n, const float4& val) {
+            if (m < Sk) *reinterpret_cast<float4*>(dK + ((size_t)b * Sk + m) * ldk + h * D + n) = val;
+        });
     }
-    __syncthreads();
-    // ---- dQ = dS K: rows ty + 16 i, columns 4 tx .. 4 tx + 3
-    for (int r0 = 0; r0 < Sq; r0 += 64) {
-        const int no = min(tx * 4, D - 4);
-        float acc[4][4] = {};
-        int ra[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = min(r0 + ty + 16 * i, Sq - 1) * LP;
-        for (int kk = 0; kk < Sk4; kk += 4) {
-            float4 a[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = ld4(P + ra[i] + kk);
-            const float4 b0 = ld4(k + min(kk, Sk - 1) * LD + no), b1 = ld4(k + min(kk + 1, Sk - 1) * LD + no),
-                         b2 = ld4(k + min(kk + 2, Sk - 1) * LD + no), b3 = ld4(k + min(kk + 3, Sk - 1) * LD + no);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { fma4(acc[i], a[i].x, b0); fma4(acc[i], a[i].y, b1); fma4(acc[i], a[i].z, b2); fma4(acc[i], a[i].w, b3); }
-        }
-        if (no == tx * 4)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = r0 + ty + 16 * i;
-                if (r < Sq) *reinterpret_cast<float4*>(dQ + ((size_t)b * Sq + r) * ldq + h * D + no) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
-            }
-    }
-    // ---- dK = dS^T Q
-    mm_tn(P, LP, q, LD, Sk4, D, Sq, ty, tx, [&](int m, int n, const float4& val) {
-        if (m < Sk) *reinterpret_cast<float4*>(dK + ((size_t)b * Sk + m) * ldk + h * D + n) = val;
-    });
 }
 
-extern "C" int didi_attention_backward(const float* Q, const float* K, const float* V, const float* dO, const int32_t* key_mask, int B, int heads,
-                                       int Sq, int Sk, int D, int ldq, int ldk, int ldv, int ldo, int causal, float scale, float* dQ, float* dK,
-                                       float* dV, void* stream) {
-    DIDI_CHECK_ARG(Q && K && V && dO && dQ && dK && dV && B >= 0 && heads > 0 && Sq > 0 && Sk > 0 && D > 0);
-    if (Sq > 96 || Sk > 96 || D > 64 || D % 4 != 0) return DIDI_ERR_UNSUPPORTED;
-    if (causal && Sq != Sk) return DIDI_ERR_BAD_ARG;
+static int attention_train_launch(const didi_attn_train_args* a, bool bwd, void* stream) {
+    DIDI_CHECK_ARG(a && a->Q && a->K && a->V && a->B >= 0 && a->heads > 0 && a->Sq > 0 && a->Sk > 0 && a->D > 0);
+    DIDI_CHECK_ARG(a->drop_p >= 0.f && a->drop_p < 1.f);
+    if (bwd) DIDI_CHECK_ARG(a->dO && a->dQ && a->dK && a->dV);
+    else DIDI_CHECK_ARG(a->O);
+    if (a->Sq > 96 || a->Sk > 96 || a->D > 64 || a->D % 4 != 0) return DIDI_ERR_UNSUPPORTED;
+    if (a->causal && a->Sq != a->Sk) return DIDI_ERR_BAD_ARG;
     // 16-byte loads and stores of head slices: leading dimensions in multiples of 4 floats, bases 16-byte aligned
-    DIDI_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && ldq >= heads * D && ldk >= heads * D && ldv >= heads * D &&
-                   ldo >= heads * D);
-    for (const void* ptr : {(const void*)Q, (const void*)K, (const void*)V, (const void*)dO, (const void*)dQ, (const void*)dK, (const void*)dV})
+    const int hd = a->heads * a->D;
+    DIDI_CHECK_ARG(a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->ldv % 4 == 0 && a->ldo % 4 == 0 && a->ldq >= hd && a->ldk >= hd && a->ldv >= hd && a->ldo >= hd);
+    for (const void* ptr : {(const void*)a->Q, (const void*)a->K, (const void*)a->V, (const void*)a->dO, (const void*)a->O, (const void*)a->dQ,
+                            (const void*)a->dK, (const void*)a->dV})
         DIDI_CHECK_ARG(reinterpret_cast<uintptr_t>(ptr) % 16 == 0);
-    if (B == 0) return DIDI_OK;
-    const int LD = D + 4, LP = ((Sk + 3) & ~3) + 4;
-    const size_t lds = sizeof(float) * ((size_t)2 * Sq * LD + (size_t)2 * Sk * LD + (size_t)Sq * LP);
+    if (a->B == 0) return DIDI_OK;
+    const int LD = a->D + 4, LP = ((a->Sk + 3) & ~3) + 4;
+    const size_t lds = sizeof(float) * ((size_t)(bwd ? 2 : 1) * a->Sq * LD + (size_t)2 * a->Sk * LD + (size_t)a->Sq * LP);
     if (lds > 160 * 1024 - 256) return DIDI_ERR_UNSUPPORTED;
     static std::mutex mu;
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_backward_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_backward_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
-            return DIDI_ERR_LAUNCH;
+        for (const void* fn : {reinterpret_cast<const void*>(&attention_train_kernel<4, true>), reinterpret_cast<const void*>(&attention_train_kernel<6, true>),
+                               reinterpret_cast<const void*>(&attention_train_kernel<4, false>), reinterpret_cast<const void*>(&attention_train_kernel<6, false>)})
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return DIDI_ERR_LAUNCH;
     }
-    const float sc = scale > 0.f ? scale : 1.0f / sqrtf((float)D);
-    if (Sk <= 64)
-        attention_backward_kernel<4><<<dim3(heads, B), 256, lds, as_stream(stream)>>>(Q, K, V, dO, key_mask, Sq, Sk, D, ldq, ldk, ldv, ldo, causal, sc, dQ, dK, dV);
-    else
-        attention_backward_kernel<6><<<dim3(heads, B), 256, lds, as_stream(stream)>>>(Q, K, V, dO, key_mask, Sq, Sk, D, ldq, ldk, ldv, ldo, causal, sc, dQ, dK, dV);
+    didi_attn_train_args p = *a;
+    if (!(p.scale > 0.f)) p.scale = 1.0f / sqrtf((float)a->D);
+    const dim3 grid(a->heads, a->B);
+    hipStream_t st = as_stream(stream);
+    if (bwd) {
+        if (a->Sk <= 64) attention_train_kernel<4, true><<<grid, 256, lds, st>>>(p);
+        else attention_train_kernel<6, true><<<grid, 256, lds, st>>>(p);
+    } else {
+        if (a->Sk <= 64) attention_train_kernel<4, false><<<grid, 256, lds, st>>>(p);
+        else attention_train_kernel<6, false><<<grid, 256, lds, st>>>(p);
+    }
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+extern "C" int didi_attention_train_forward(const didi_attn_train_args* a, void* stream) { return attention_train_launch(a, false, stream); }
+extern "C" int didi_attention_train_backward(const didi_attn_train_args* a, void* stream) { return attention_train_launch(a, true, stream); }
+
+extern "C" int didi_attention_backward(const float* Q, const float* K, const float* V, const float* dO, const int32_t* key_mask, int B, int heads,
+                                       int Sq, int Sk, int D, int ldq, int ldk, int ldv, int ldo, int causal, float scale, float* dQ, float* dK,
+                                       float* dV, void* stream) {
+    didi_attn_train_args a{};
+    a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.key_mask = key_mask;
+    a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.D = D;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.causal = causal; a.scale = scale;
+    a.dQ = dQ; a.dK = dK; a.dV = dV;
+    return attention_train_launch(&a, true, stream);
+}
+
+// ------------------------------------------------------------------ hidden dropout (BertEmbeddings / BertSelfOutput / BertOutput)
+// out = x o mask / (1 - p) + residual; mask of flat element e: word (e & 3) of Philox4x32-10(offset + e / 4, seed) >= p 2^32.
+// The backward is the same call on the gradient (residual = NULL) with the same (seed, offset).
+__global__ void __launch_bounds__(256) dropout_add_kernel(const float* x, const float* residual, size_t n4, float p, uint64_t seed,
+                                                          uint64_t offset, float* out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const uint32_t thr = (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f);
+    const float inv_keep = 1.0f / (1.0f - p);
+    uint32_t w[4];
+    philox4x32_10(offset + i, seed, w);
+    float4 t = reinterpret_cast<const float4*>(x)[i];
+    t.x = w[0] < thr ? 0.f : t.x * inv_keep;
+    t.y = w[1] < thr ? 0.f : t.y * inv_keep;
+    t.z = w[2] < thr ? 0.f : t.z * inv_keep;
+    t.w = w[3] < thr ? 0.f : t.w * inv_keep;
+    if (residual) {
+        const float4 r = reinterpret_cast<const float4*>(residual)[i];
+        t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = t;
+}
+extern "C" int didi_dropout_add(const float* x, const float* residual, size_t n, float p, uint64_t seed, uint64_t offset, float* out, void* stream) {
+    DIDI_CHECK_ARG(x && out && n % 4 == 0 && p >= 0.f && p < 1.f);
+    if (n == 0) return DIDI_OK;
+    dropout_add_kernel<<<(unsigned)cdiv((long)(n / 4), 256), 256, 0, as_stream(stream)>>>(x, residual, n / 4, p, seed, offset, out);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

@@ -27,6 +27,12 @@ from .schedule import configure_schedule
 # T = 2000, sqrt schedule: t > 700 / t > 128 / the rest): one product while the input is mostly fresh noise, the weights'
 # remainder once x_t starts to carry the previous estimate, all three products for the last steps.
 DEFAULT_SCHEDULE = ((0.35, "fp16"), (0.064, "fp16x2"), (0, "fp16x3"))
+# The loop forgets an earlier error per CALL, not per unit of t: with step_freq > 1 the timestep thresholds leave too few calls
+# in the precise regime (T = 2000, f = 10: 13 calls of fp16x3 -> the final x_t is 4.6e-4 off and 4 of 2048 ids differ; with 32
+# calls 6.5e-5 / 0, with 64 calls 8e-6 / 0: tests/sched_probe_f10.py, profiles/r02_sched_probe_f10_ddpm.log).  Floors applied
+# after the timestep rule, as (calls_from_the_end, precision): the last n calls run at least that precision.
+DEFAULT_TAIL_CALLS = ((64, "fp16x3"),)
+_RANK = {"fp16": 0, "fp16x2": 1, "fp16x3": 2}
 
 
 class _Planes:
@@ -70,14 +76,17 @@ class _Classifier:
 
 
 class DiDiSampler:
-    def __init__(self, state_dict, cfg: DiDiConfig, device="cuda", precision="bf16x3", schedule=None):
+    def __init__(self, state_dict, cfg: DiDiConfig, device="cuda", precision="bf16x3", schedule=None, tail_calls=None):
         """``precision``: bf16 | fp16 (one MFMA product), fp16x2 (weights with their remainder), bf16x3 (fp32-class), or
         "fp16-sched": fp16 planes with the default precision schedule ``DEFAULT_SCHEDULE``.
         ``schedule``: precision schedule of ``sample`` over the TIMESTEP of each denoiser call, a tuple of (t_above, precision)
         pairs in decreasing t: a call whose time-embedding row is > t_above runs in that precision (fp16 | fp16x2 | fp16x3);
-        the last pair must have t_above = 0.  Needs an fp16-plane ``precision``."""
+        the last pair must have t_above = 0.  Needs an fp16-plane ``precision``.
+        ``tail_calls``: (calls_from_the_end, precision) floors on top of the schedule: the last n calls of a loop run at least
+        that precision ("fp16-sched" defaults to ``DEFAULT_TAIL_CALLS``; an explicit schedule to none)."""
         if precision == "fp16-sched":
             precision, schedule = "fp16x2", (schedule or DEFAULT_SCHEDULE)
+            tail_calls = DEFAULT_TAIL_CALLS if tail_calls is None else tail_calls
         if precision not in ("bf16", "fp16", "fp16x2", "bf16x3"):
             raise ValueError("precision must be one of bf16, fp16, fp16x2, bf16x3, fp16-sched")
         if schedule is not None:  # thresholds below 1 are fractions of T
@@ -96,6 +105,9 @@ class DiDiSampler:
                 raise ValueError("a precision schedule needs fp16-plane precisions and (t_above, precision) pairs in decreasing t ending at 0")
         self.cfg, self.device, self.precision = cfg, torch.device(device), precision
         self.schedule = schedule
+        self.tail_calls = tuple(tail_calls or ())  # an explicit schedule is taken as written unless floors are given too
+        if self.tail_calls and (not schedule or any(p not in _RANK or n < 0 for n, p in self.tail_calls)):
+            raise ValueError("tail_calls = (calls_from_the_end, fp16|fp16x2|fp16x3) pairs, and only together with a schedule")
         sd = state_dict
         dev = self.device
         f = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
@@ -337,7 +349,14 @@ class DiDiSampler:
         """C-ABI precision of every denoiser call of a loop, from the timestep (time-embedding row) of each; None = uniform."""
         if not self.schedule:
             return None
-        return [ops.PRECISIONS[next(p for t_above, p in self.schedule if t > t_above)] for t in time_rows]
+        names = [next(p for t_above, p in self.schedule if t > t_above) for t in time_rows]
+        n = len(names)
+        for k in range(n):
+            from_end = n - 1 - k
+            for floor_calls, p in self.tail_calls:
+                if from_end < floor_calls and _RANK[p] > _RANK[names[k]]:
+                    names[k] = p
+        return [ops.PRECISIONS[p] for p in names]
 
     def round_operands(self, x0_hi, x0_lo):
         """(x_hi, x_lo or None, precision) for ops.round_argmax / ops.round_ce on x0 planes."""

@@ -509,11 +509,35 @@ int didi_axpby(float a, const float* x, float b, float* y, size_t n, void* strea
 int didi_ce_backward(float* logits, const int64_t* targets, const int64_t* mask, int M, int V, float scale, float* nll, void* stream);
 /* nn.Embedding backward: grad[ids[m], :] += scale * dy[m, :] (float atomics); rows with id == skip_id (padding_idx) get none. */
 int didi_embedding_backward(const int64_t* ids, const float* dy, int M, int H, float scale, int64_t skip_id, float* grad, void* stream);
-/* Attention backward (fp32 operands addressed as didi_attention addresses its planes; P is recomputed): dQ, dK, dV from dO.
- * Sq, Sk <= 96, D <= 64.  A correctness-level first version (fp32 FMA loops in LDS); the sampler never runs it. */
+/* Attention backward without dropout (= didi_attention_train_backward with drop_p = 0): dQ, dK, dV from dO, P recomputed. */
 int didi_attention_backward(const float* Q, const float* K, const float* V, const float* dO, const int32_t* key_mask, int B, int heads,
                             int Sq, int Sk, int D, int ldq, int ldk, int ldv, int ldo, int causal, float scale, float* dQ, float* dK,
                             float* dV, void* stream);
+/* Attention of the TRAINING step in fp32 (forward and backward share one mask definition for attention-probability dropout,
+ * HF:models/bert/modeling_bert.py:129): O = dropout(softmax(Q K^T scale + masks)) V and its backward.  Operands fp32, addressed
+ * as didi_attention addresses its planes ([B*S, ld] row-major, head h at columns h*D..); Sq, Sk <= 96, D <= 64, D % 4 == 0,
+ * leading dimensions % 4 == 0, bases 16-byte aligned.  Dropout: element (b, h, i, j) is dropped iff word (j & 3) of
+ * Philox4x32-10(counter = offset + (((b heads + h) Sq + i) Sk4 + j) / 4, key = seed) < drop_p 2^32 (Sk4 = Sk rounded up to 4);
+ * the backward must be given the forward's (drop_p, seed, offset).  The sampler never runs these. */
+typedef struct didi_attn_train_args {
+    const float *Q, *K, *V;   /* fp32 operands */
+    const float* dO;          /* backward: gradient of O, [B*Sq, ldo] */
+    const int32_t* key_mask;  /* [B, Sk] or NULL */
+    int B, heads, Sq, Sk, D;
+    int ldq, ldk, ldv, ldo;
+    int causal;
+    float scale;              /* 0 = 1/sqrt(D) */
+    float drop_p;             /* 0 = no dropout */
+    uint64_t seed, offset;
+    float* O;                 /* forward output [B*Sq, ldo] */
+    float *dQ, *dK, *dV;      /* backward outputs, laid out like Q, K, V */
+} didi_attn_train_args;
+int didi_attention_train_forward(const didi_attn_train_args* a, void* stream);
+int didi_attention_train_backward(const didi_attn_train_args* a, void* stream);
+/* Hidden dropout + residual (BertEmbeddings / BertSelfOutput / BertOutput, HF:models/bert/modeling_bert.py:107,291,349):
+ * out = x o mask / (1 - p) + residual (nullable); flat element e is dropped iff word (e & 3) of
+ * Philox4x32-10(offset + e / 4, seed) < p 2^32.  Backward = the same call on the gradient with residual = NULL. n % 4 == 0. */
+int didi_dropout_add(const float* x, const float* residual, size_t n, float p, uint64_t seed, uint64_t offset, float* out, void* stream);
 /* torch.optim.AdamW step (src/diffusion/model.py:136-158: AdamW(lr = 1) x LambdaLR, so `lr` is the schedule's value) on one
  * parameter tensor, gradient pre-scaled by *gscale (device scalar or NULL: the clipping coefficient, configs/train.yaml:45). */
 int didi_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,

@@ -346,6 +346,19 @@ def test_precision_schedule(name):
     assert all(torch.equal(a, b) for a, b in zip(plain_tr[: k0 + 1], part_tr[: k0 + 1])), "calls before the switch are untouched"
     if k0 + 1 < n_calls:
         assert not torch.equal(plain_tr[k0 + 1], part_tr[k0 + 1]), "the first fp16x3 call changes the next input"
+    # tail floors: the last n calls of a loop run at least the named precision, whatever their timestep ("fp16-sched" default: 64)
+    from didi_amd.model import DEFAULT_TAIL_CALLS
+    sched = DiDiSampler(w, cfg, device="cuda", precision="fp16-sched")
+    assert sched.tail_calls == DEFAULT_TAIL_CALLS and part.tail_calls == ()
+    rows = list(range(2000, 1, -10)) + [1]
+    sched.schedule = ((700, "fp16"), (128, "fp16x2"), (0, "fp16x3"))  # the default's thresholds at T = 2000
+    precs = sched.call_precisions(rows)
+    assert precs.count(5) == 64 and all(p == 5 for p in precs[-64:]) and precs.count(2) == 130 and precs.count(4) == 7
+    floor = DiDiSampler(w, cfg, device="cuda", precision="fp16x2", schedule=((0, "fp16x2"),), tail_calls=((1, "fp16x3"),))
+    precs = floor.call_precisions(plan.time_row)
+    assert precs[-1] == 5 and all(p == 4 for p in precs[:-1])
+    with pytest.raises(ValueError):
+        DiDiSampler(w, cfg, device="cuda", precision="fp16x2", tail_calls=((4, "fp16x3"),))
     for bad in (dict(precision="bf16x3", schedule=((0, "fp16x3"),)), dict(precision="fp16", schedule=((5, "fp16"),)),
                 dict(precision="fp16", schedule=((5, "fp16"), (9, "fp16x2"), (0, "fp16x3")))):
         with pytest.raises(ValueError):

@@ -154,7 +154,7 @@ def main_training(args):
     dev = torch.device("cuda", local_rank)
     cfg = DiDiConfig(diffusion_steps=args.diffusion_steps, **({"vocab": args.vocab} if args.vocab else {}))
     sd = synthetic_state_dict(cfg, seed=1234)
-    tr = DiDiTrainer(sd, cfg, device=dev, precision=args.train_precision)
+    tr = DiDiTrainer(sd, cfg, device=dev, precision=args.train_precision, hidden_dropout=0.1, attention_dropout=0.1)  # train.yaml:22-23
     B, S = args.batch, args.seq
     n_batches = 4
     batches = []
@@ -212,7 +212,7 @@ def main_training(args):
         "config": {
             "workload": (f"BASELINE configs[4] (training step): blenderbot-400M-distill-sized frozen encoder + BertConfig-default decoder "
                          f"(12x768/12h/3072), V={cfg.vocab}, T={cfg.diffusion_steps}, batch {B}/GPU, context {S}, target {S}, AdamW + linear LR + clip 1.0, "
-                         f"dropout 0 (the reference's train.yaml uses 0.1: not implemented, DESIGN.md section 8)"),
+                         f"decoder dropout 0.1 / 0.1 (configs/train.yaml:22-23)"),
             "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world} (bucketed gradient all-reduce + 5 metric scalars in the last bucket)",
             "trainable_parameters": n_params, "precision": args.train_precision,
             "world_size_seen": torch.distributed.get_world_size() if world > 1 else 1,

@@ -66,6 +66,16 @@ class AttnArgs(C.Structure):
     ]
 
 
+class AttnTrainArgs(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("dO", C.c_void_p), ("key_mask", C.c_void_p),
+        ("B", C.c_int), ("heads", C.c_int), ("Sq", C.c_int), ("Sk", C.c_int), ("D", C.c_int),
+        ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int), ("causal", C.c_int),
+        ("scale", C.c_float), ("drop_p", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64),
+        ("O", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p),
+    ]
+
+
 class Linear(C.Structure):
     _fields_ = [("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("bias", C.c_void_p), ("N", C.c_int), ("K", C.c_int)]
 

@@ -385,22 +385,51 @@ def embedding_backward(ids, dy, grad, scale=1.0, skip_id=-1):
     return grad
 
 
-def attention_backward(q, k, v, dO, heads, causal=False, key_mask=None, scale=None, out=None):
-    """fp32 q [B,Sq,heads*D], k/v [B,Sk,heads*D] (row-strided views of a fused projection are fine), dO [B,Sq,heads*D] contiguous
-    -> (dq, dk, dv).  ``out``: views to write into, strided exactly like q, k, v (e.g. the thirds of one [B,S,3H] buffer, which
-    is then the gradient of the fused projection's output); default: fresh contiguous tensors (needs contiguous q, k, v)."""
+def _attn_train_args(q, k, v, heads, causal, key_mask, scale, drop_p, seed, offset):
     B, Sq, HD = q.shape
     Sk = k.shape[1]
+    for t_, s_ in ((q, Sq), (k, Sk), (v, Sk)):
+        assert t_.dtype == torch.float32 and t_.stride(2) == 1 and t_.stride(0) == s_ * t_.stride(1), "operands must be [B*S, ld] row-major"
+    a = _lib.AttnTrainArgs()
+    a.Q, a.K, a.V, a.key_mask = q.data_ptr(), k.data_ptr(), v.data_ptr(), _lib.ptr(key_mask)
+    a.B, a.heads, a.Sq, a.Sk, a.D = B, heads, Sq, Sk, HD // heads
+    a.ldq, a.ldk, a.ldv, a.ldo, a.causal = q.stride(1), k.stride(1), v.stride(1), HD, int(causal)
+    a.scale, a.drop_p, a.seed, a.offset = (0.0 if scale is None else float(scale)), float(drop_p), int(seed), int(offset)
+    return a
+
+
+def attention_train(q, k, v, heads, causal=False, key_mask=None, scale=None, drop_p=0.0, seed=0, offset=0):
+    """Training-step attention in fp32: O = dropout(softmax(q k^T scale + masks)) v -> fp32 [B, Sq, heads*D] contiguous.
+    q/k/v fp32 [B, S, heads*D] (row-strided views of a fused projection are fine)."""
+    a = _attn_train_args(q, k, v, heads, causal, key_mask, scale, drop_p, seed, offset)
+    out = torch.empty((a.B, a.Sq, a.heads * a.D), dtype=torch.float32, device=q.device)
+    a.O = out.data_ptr()
+    _lib.check(lib.didi_attention_train_forward(C.byref(a), _lib.current_stream()), "attention_train_forward")
+    return out
+
+
+def attention_backward(q, k, v, dO, heads, causal=False, key_mask=None, scale=None, out=None, drop_p=0.0, seed=0, offset=0):
+    """Backward of ``attention_train`` (same drop_p / seed / offset as the forward): dO [B,Sq,heads*D] contiguous -> (dq, dk, dv).
+    ``out``: views to write into, strided exactly like q, k, v (e.g. the thirds of one [B,S,3H] buffer, which is then the
+    gradient of the fused projection's output); default: fresh contiguous tensors (needs contiguous q, k, v)."""
     dO = _f32c(dO)
+    a = _attn_train_args(q, k, v, heads, causal, key_mask, scale, drop_p, seed, offset)
     if out is None:
         out = tuple(torch.empty(t_.shape, dtype=torch.float32, device=q.device) for t_ in (q, k, v))
-    for t_, g_, s in ((q, out[0], Sq), (k, out[1], Sk), (v, out[2], Sk)):
-        assert t_.dtype == torch.float32 and t_.stride(2) == 1 and t_.stride(0) == s * t_.stride(1), "operands must be [B*S, ld] row-major"
+    for t_, g_ in zip((q, k, v), out):
         assert g_.dtype == torch.float32 and g_.stride() == t_.stride() and g_.shape == t_.shape, "gradients are laid out like their operands"
-    _lib.check(lib.didi_attention_backward(q.data_ptr(), k.data_ptr(), v.data_ptr(), dO.data_ptr(), _lib.ptr(key_mask), B, heads, Sq, Sk,
-                                           HD // heads, q.stride(1), k.stride(1), v.stride(1), HD, int(causal),
-                                           0.0 if scale is None else float(scale), out[0].data_ptr(), out[1].data_ptr(),
-                                           out[2].data_ptr(), _lib.current_stream()), "attention_backward")
+    a.dO, a.dQ, a.dK, a.dV = dO.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()
+    _lib.check(lib.didi_attention_train_backward(C.byref(a), _lib.current_stream()), "attention_train_backward")
+    return out
+
+
+def dropout_add(x, residual, p, seed, offset):
+    """x o mask / (1 - p) + residual (or None) -> fp32, Philox mask keyed (seed, offset); the backward is the same call on dy."""
+    x = _f32c(x)
+    r = None if residual is None else _f32c(residual)
+    out = torch.empty_like(x)
+    _lib.check(lib.didi_dropout_add(x.data_ptr(), _lib.ptr(r), x.numel(), float(p), int(seed), int(offset), out.data_ptr(),
+                                    _lib.current_stream()), "dropout_add")
     return out
 
 

@@ -9,8 +9,11 @@ torch owns the memory and does the B-element scalar arithmetic (per-dialog means
 What is trained: everything but the frozen context encoder (model.py:114-115): emb, time_embeds, classifier (or tied), adapter,
 the decoder.  ``decoder.embeddings.word_embeddings`` and ``decoder.pooler`` never receive a gradient in the reference (inputs
 arrive as ``inputs_embeds``; the pooler output is unused), AdamW skips them, and so does this trainer.
-Dropout: the decoder's hidden / attention-probability dropout (configs/train.yaml:22-23) is NOT applied (p = 0, the setting the
-gradient fixtures in tests/golden/train_tiny_* were made with); see DESIGN.md section 8.
+Dropout (configs/train.yaml:22-23: hidden_dropout_prob / attention_probs_dropout_prob of the decoder's BertConfig): applied at
+HF's sites -- after the embeddings LayerNorm, on the attention probabilities of self- and cross-attention, after each of the three
+output projections before the residual -- with Philox masks regenerated in the backward from (seed, site offset); p = 0 (the
+default, and the setting of the gradient fixtures) skips the kernels.  The masks cannot equal torch's generator stream, so with
+p > 0 parity is statistical plus exact agreement with a torch emulation fed the same masks (tests/test_gpu_trainer.py).
 """
 import math
 
@@ -62,8 +65,9 @@ class DiDiTrainer:
     forward and backward; the frozen encoder always runs bf16x3."""
 
     def __init__(self, state_dict, cfg, device="cuda", precision="bf16x3", anchor_loss=False, noise_factor=1.0, opt_kwargs=None,
-                 gradient_clip_val=1.0):
+                 gradient_clip_val=1.0, hidden_dropout=0.0, attention_dropout=0.0):
         self.cfg, self.device, self.precision = cfg, torch.device(device), precision
+        self.hidden_dropout, self.attention_dropout = float(hidden_dropout), float(attention_dropout)
         self.anchor_loss, self.noise_factor = bool(anchor_loss), float(noise_factor)
         self.opt = dict(DEFAULT_OPT, **(opt_kwargs or {}))
         self.clip = gradient_clip_val
@@ -155,11 +159,12 @@ class DiDiTrainer:
         return ops.linear_backward(dC, A, w.w, precision=self.precision)
 
     @torch.no_grad()
-    def forward_backward(self, raw_context, target, *, draws=None, t=None, keep=False):
+    def forward_backward(self, raw_context, target, *, draws=None, t=None, keep=False, dropout_seed=None):
         """One ``training_step`` and its backward -> dict(mse, ce, t_T, loss, ce_hat [0-dim device tensors], grads {name: fp32}).
 
         ``draws`` / ``t``: injected normal draws [n0, n1] and timesteps (parity tests), else Philox noise / ``torch.randint`` as
-        the reference draws them.  ``keep``: also return the tensors the tests compare (x_0, x_t, x_0_hat, d x_0_hat)."""
+        the reference draws them.  ``keep``: also return the tensors the tests compare (x_0, x_t, x_0_hat, d x_0_hat).
+        ``dropout_seed``: key of the step's dropout masks (default: drawn from torch's global generator)."""
         cfg, dev, P = self.cfg, self.device, self.params
         ids, tmask = target.input_ids.to(dev), target.attention_mask.to(dev)
         cids, cmask = raw_context.input_ids.to(dev), raw_context.attention_mask.to(dev)
@@ -170,6 +175,18 @@ class DiDiTrainer:
         eps = cfg.dec_ln_eps
         pd = self._pd
         G = {}
+        ph, pa = self.hidden_dropout, self.attention_dropout
+        dseed = 0
+        if ph > 0 or pa > 0:
+            dseed = int(dropout_seed) if dropout_seed is not None else int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+        n_sites = [0]
+
+        def site():  # a disjoint Philox counter range per dropout site of the step (2^34 counters = 2^36 elements each)
+            n_sites[0] += 1
+            return n_sites[0] << 34
+
+        def drop(x, residual, off):  # hidden dropout (+ residual), or its backward with residual = None
+            return ops.dropout_add(x, residual, ph, dseed, off)
         # ---- noising (model.py:202-207)
         emb = ops.embed_gather(ids, P["emb.weight"])
         seed = 0
@@ -201,35 +218,54 @@ class DiDiTrainer:
                                    P["decoder.embeddings.token_type_embeddings.weight"][0].contiguous())
         h_hi, h_lo, h = ops.layernorm(x_in.view(M, H), P["decoder.embeddings.LayerNorm.weight"], P["decoder.embeddings.LayerNorm.bias"], eps,
                                       f32=True, dtype=pd)
+        off_emb = site()
+        if ph > 0:  # BertEmbeddings.dropout (HF:bert:107)
+            h = drop(h, None, off_emb)
+            h_hi, h_lo = ops.split(h, dtype=pd)
         saved = []
         x3 = self.precision in ("bf16x3", "fp16x3")
-        ap = self.precision  # attention precision
         for li, (L, ln) in enumerate(zip(self._lin, self._layer_names)):
             s = dict(h0=h)
-            qkv_hi, qkv_lo, qkv = self._linear(L["qkv"], h_hi, h_lo)
-            v3 = lambda t_, i: None if t_ is None else t_.view(B, S, 3 * H)[:, :, i * H:(i + 1) * H]  # noqa: E731
-            a_hi, a_lo = ops.attention(*(((v3(qkv_hi, i), v3(qkv_lo, i))) for i in range(3)), A, causal=True, precision=ap)
-            a_hi = a_hi.view(M, H)
-            a_lo = None if a_lo is None else a_lo.view(M, H)
-            s["qkv"], s["att"] = qkv, ops.join(a_hi, a_lo)
-            _, _, s1 = self._linear(L["o"], a_hi, a_lo if a_lo is not None else None, residual=h, out_planes=False)
+            _, _, qkv = self._linear(L["qkv"], h_hi, h_lo, out_planes=False)
+            q3 = qkv.view(B, S, 3 * H)
+            s["off_sa"] = site()
+            att = ops.attention_train(q3[:, :, :H], q3[:, :, H:2 * H], q3[:, :, 2 * H:], A, causal=True, drop_p=pa, seed=dseed,
+                                      offset=s["off_sa"]).view(M, H)
+            a_hi, a_lo = ops.split(att, dtype=pd)
+            s["qkv"], s["att"] = qkv, att
+            s["off_o"] = site()
+            if ph > 0:  # BertSelfOutput: LayerNorm(dropout(dense(x)) + input)
+                _, _, y = self._linear(L["o"], a_hi, a_lo, out_planes=False)
+                s1 = drop(y, h, s["off_o"])
+            else:
+                _, _, s1 = self._linear(L["o"], a_hi, a_lo, residual=h, out_planes=False)
             h_hi, h_lo, h1 = ops.layernorm(s1, P[ln["ln1"] + ".weight"], P[ln["ln1"] + ".bias"], eps, f32=True, dtype=pd)
             s["s1"], s["h1"] = s1, h1
-            cq_hi, cq_lo, cq = self._linear(L["cq"], h_hi, h_lo)
-            ckv_hi, ckv_lo, ckv = self._linear(L["ckv"], x_hi, x_lo)
-            v2 = lambda t_, i: None if t_ is None else t_.view(B, Cn, 2 * H)[:, :, i * H:(i + 1) * H]  # noqa: E731
-            ca_hi, ca_lo = ops.attention((cq_hi.view(B, S, H), cq_lo.view(B, S, H)), (v2(ckv_hi, 0), v2(ckv_lo, 0)),
-                                         (v2(ckv_hi, 1), v2(ckv_lo, 1)), A, causal=False, key_mask=mask32, precision=ap)
-            ca_hi = ca_hi.view(M, H)
-            ca_lo = None if ca_lo is None else ca_lo.view(M, H)
-            s["cq"], s["ckv"], s["catt"] = cq, ckv, ops.join(ca_hi, ca_lo)
-            _, _, s2 = self._linear(L["co"], ca_hi, ca_lo, residual=h1, out_planes=False)
+            _, _, cq = self._linear(L["cq"], h_hi, h_lo, out_planes=False)
+            _, _, ckv = self._linear(L["ckv"], x_hi, x_lo, out_planes=False)
+            kv3 = ckv.view(B, Cn, 2 * H)
+            s["off_ca"] = site()
+            catt = ops.attention_train(cq.view(B, S, H), kv3[:, :, :H], kv3[:, :, H:], A, causal=False, key_mask=mask32, drop_p=pa,
+                                       seed=dseed, offset=s["off_ca"]).view(M, H)
+            ca_hi, ca_lo = ops.split(catt, dtype=pd)
+            s["cq"], s["ckv"], s["catt"] = cq, ckv, catt
+            s["off_co"] = site()
+            if ph > 0:
+                _, _, y = self._linear(L["co"], ca_hi, ca_lo, out_planes=False)
+                s2 = drop(y, h1, s["off_co"])
+            else:
+                _, _, s2 = self._linear(L["co"], ca_hi, ca_lo, residual=h1, out_planes=False)
             h_hi, h_lo, h2 = ops.layernorm(s2, P[ln["ln2"] + ".weight"], P[ln["ln2"] + ".bias"], eps, f32=True, dtype=pd)
             s["s2"], s["h2"] = s2, h2
             _, _, u = self._linear(L["up"], h_hi, h_lo, out_planes=False)
             f_hi, f_lo, f_ = self._gelu_planes(u)
             s["u"], s["f"] = u, f_
-            _, _, s3 = self._linear(L["down"], f_hi, f_lo, residual=h2, out_planes=False)
+            s["off_down"] = site()
+            if ph > 0:
+                _, _, y = self._linear(L["down"], f_hi, f_lo, out_planes=False)
+                s3 = drop(y, h2, s["off_down"])
+            else:
+                _, _, s3 = self._linear(L["down"], f_hi, f_lo, residual=h2, out_planes=False)
             h_hi, h_lo, h = ops.layernorm(s3, P[ln["ln3"] + ".weight"], P[ln["ln3"] + ".bias"], eps, f32=True, dtype=pd)
             s["s3"] = s3
             saved.append(s)
@@ -292,7 +328,7 @@ class DiDiTrainer:
 
             ds3, dg, db = ops.layernorm_backward(dh, s["s3"], P[ln["ln3"] + ".weight"], eps)
             put(ln["ln3"], dg, db)
-            df, dW, dbias = self._linear_bwd(ds3, s["f"], L["down"])
+            df, dW, dbias = self._linear_bwd(drop(ds3, None, s["off_down"]) if ph > 0 else ds3, s["f"], L["down"])
             put(ln["down"], dW, dbias)
             du = ops.act_backward("gelu", df, s["u"])
             dh2, dW, dbias = self._linear_bwd(du, s["h2"], L["up"])
@@ -300,13 +336,13 @@ class DiDiTrainer:
             ops.axpby(1.0, ds3, 1.0, dh2)
             ds2, dg, db = ops.layernorm_backward(dh2, s["s2"], P[ln["ln2"] + ".weight"], eps)
             put(ln["ln2"], dg, db)
-            dcatt, dW, dbias = self._linear_bwd(ds2, s["catt"], L["co"])
+            dcatt, dW, dbias = self._linear_bwd(drop(ds2, None, s["off_co"]) if ph > 0 else ds2, s["catt"], L["co"])
             put(ln["co"], dW, dbias)
             ckv = s["ckv"].view(B, Cn, 2 * H)
             dckv = torch.empty_like(ckv)
             dcq = torch.empty((B, S, H), dtype=torch.float32, device=dev)
             ops.attention_backward(s["cq"].view(B, S, H), ckv[:, :, :H], ckv[:, :, H:], dcatt.view(B, S, H), A, causal=False, key_mask=mask32,
-                                   out=(dcq, dckv[:, :, :H], dckv[:, :, H:]))
+                                   out=(dcq, dckv[:, :, :H], dckv[:, :, H:]), drop_p=pa, seed=dseed, offset=s["off_ca"])
             dh1, dW, dbias = self._linear_bwd(dcq.view(M, H), s["h1"], L["cq"])
             put(ln["cq"], dW, dbias)
             ops.axpby(1.0, ds2, 1.0, dh1)
@@ -317,12 +353,12 @@ class DiDiTrainer:
                 ops.axpby(1.0, dctx_l, 1.0, dctx)
             ds1, dg, db = ops.layernorm_backward(dh1, s["s1"], P[ln["ln1"] + ".weight"], eps)
             put(ln["ln1"], dg, db)
-            datt, dW, dbias = self._linear_bwd(ds1, s["att"], L["o"])
+            datt, dW, dbias = self._linear_bwd(drop(ds1, None, s["off_o"]) if ph > 0 else ds1, s["att"], L["o"])
             put(ln["o"], dW, dbias)
             qkv = s["qkv"].view(B, S, 3 * H)
             dqkv = torch.empty_like(qkv)
             ops.attention_backward(qkv[:, :, :H], qkv[:, :, H:2 * H], qkv[:, :, 2 * H:], datt.view(B, S, H), A, causal=True,
-                                   out=(dqkv[:, :, :H], dqkv[:, :, H:2 * H], dqkv[:, :, 2 * H:]))
+                                   out=(dqkv[:, :, :H], dqkv[:, :, H:2 * H], dqkv[:, :, 2 * H:]), drop_p=pa, seed=dseed, offset=s["off_sa"])
             dh0, dW, dbias = self._linear_bwd(dqkv.view(M, 3 * H), s["h0"], L["qkv"])
             for j, key in enumerate(("q", "k", "v")):
                 put(ln[key], dW[j * H:(j + 1) * H].contiguous(), dbias[j * H:(j + 1) * H].contiguous())
@@ -330,6 +366,8 @@ class DiDiTrainer:
             dh = dh0
             saved[li] = None  # free this layer's activations
         # decoder embeddings
+        if ph > 0:
+            dh = drop(dh, None, off_emb)
         dx_in, dg, db = ops.layernorm_backward(dh, x_in.view(M, H), P["decoder.embeddings.LayerNorm.weight"], eps)
         G["decoder.embeddings.LayerNorm.weight"], G["decoder.embeddings.LayerNorm.bias"] = dg, db
         gpos = torch.zeros_like(P["decoder.embeddings.position_embeddings.weight"])

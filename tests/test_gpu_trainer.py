@@ -286,3 +286,106 @@ def test_rsqrt_lr_lambda():
     assert lr_linear(51250, 1e-4, 0.0, 2500, 100000) == pytest.approx(0.5e-4)
     with pytest.raises(ValueError):
         lr_linear(3, 1e-4, None, 1, 2)
+
+
+# ------------------------------------------------------------------ dropout (configs/train.yaml:22-23)
+def _philox_words(n4, seed, offset):
+    from oracle.philox import raw_stream  # numpy Philox4x32-10, pinned by the Random123 known-answer vectors
+
+    return torch.from_numpy(raw_stream(n4, seed, offset).astype("int64"))
+
+
+def _thr(p):
+    import numpy as np
+
+    return int(min(float(np.float32(p) * np.float32(4294967296.0)), 4294967040.0))
+
+
+def test_hidden_dropout_mask_is_the_documented_philox_stream():
+    from didi_amd import ops
+
+    g = torch.Generator().manual_seed(8)
+    x, r = torch.randn(37, 64, generator=g), torch.randn(37, 64, generator=g)
+    p, seed, off = 0.1, 0x1234567855AA, 5 << 34
+    keep = (_philox_words(x.numel() // 4, seed, off).view(-1) >= _thr(p)).view(x.shape)
+    got = ops.dropout_add(x.cuda(), r.cuda(), p, seed, off)
+    assert rel_l2(got, torch.where(keep, x.double() / (1 - float(torch.tensor(p, dtype=torch.float32))), torch.zeros(())) + r.double()) <= 1e-6
+    back = ops.dropout_add(x.cuda(), None, p, seed, off)
+    assert torch.equal(back == 0, ~keep.cuda() | (x.cuda() == 0))
+    big = ops.dropout_add(torch.ones(1 << 20, device="cuda"), None, 0.2, 7, 0)
+    assert abs(float((big == 0).float().mean()) - 0.2) < 3e-3 and abs(float(big.mean()) - 1.0) < 5e-3
+    assert torch.equal(ops.dropout_add(x.cuda(), r.cuda(), 0.0, seed, off), (x + r).cuda())
+
+
+@pytest.mark.parametrize("B,heads,Sq,Sk,D,causal,masked,p", [(3, 4, 10, 10, 32, True, False, 0.1), (2, 12, 64, 64, 64, True, False, 0.2),
+                                                             (3, 4, 10, 13, 32, False, True, 0.1), (2, 3, 70, 90, 64, False, True, 0.3),
+                                                             (2, 4, 24, 24, 32, True, False, 0.0)])
+def test_attention_train_forward_backward_with_dropout_vs_autograd(B, heads, Sq, Sk, D, causal, masked, p):
+    """O = dropout(softmax(...)) V and its backward against torch autograd in fp64 fed the SAME mask, which is rebuilt on the host
+    from the documented Philox stream."""
+    from didi_amd import ops
+
+    g = torch.Generator().manual_seed(B * 1000 + Sk)
+    H = heads * D
+    q, k, v, dO = (torch.randn(B, s_, H, generator=g) for s_ in (Sq, Sk, Sk, Sq))
+    mask = torch.ones(B, Sk, dtype=torch.int32)
+    if masked:
+        for b in range(B):
+            mask[b, max(1, Sk - 1 - 3 * b):] = 0
+    seed, off = 0xBADB01, 3 << 34
+    Sk4 = (Sk + 3) // 4 * 4
+    keep = torch.ones(B, heads, Sq, Sk, dtype=torch.bool)
+    if p > 0:
+        keep = (_philox_words(B * heads * Sq * Sk4 // 4, seed, off).view(B, heads, Sq, Sk4) >= _thr(p))[..., :Sk]
+    qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    sh = lambda t, S: t.view(B, S, heads, D).transpose(1, 2)  # noqa: E731
+    s = sh(qd, Sq) @ sh(kd, Sk).transpose(-1, -2) / math.sqrt(D)
+    neg = torch.finfo(torch.float32).min
+    if masked:
+        s = s + (1.0 - mask[:, None, None, :].double()) * neg
+    if causal:
+        s = s + torch.triu(torch.full((Sq, Sk), neg, dtype=torch.float64), 1)
+    pr = torch.softmax(s, -1) * keep.double() / (1.0 - float(torch.tensor(p, dtype=torch.float32)))
+    o = (pr @ sh(vd, Sk)).transpose(1, 2).reshape(B, Sq, H)
+    o.backward(dO.double())
+    kw = dict(causal=causal, key_mask=mask.cuda() if masked else None, drop_p=p, seed=seed, offset=off)
+    got = ops.attention_train(q.cuda(), k.cuda(), v.cuda(), heads, **kw)
+    assert rel_l2(got, o.detach()) <= 2e-5
+    gq, gk, gv = ops.attention_backward(q.cuda(), k.cuda(), v.cuda(), dO.cuda(), heads, **kw)
+    assert rel_l2(gq, qd.grad) <= 2e-5 and rel_l2(gk, kd.grad) <= 2e-5 and rel_l2(gv, vd.grad) <= 2e-5
+    if p > 0:  # the mask really dropped something, at about the asked rate on the unmasked region
+        rate = 1.0 - keep.float().mean().item()
+        assert abs(rate - p) < 0.05
+
+
+def test_training_step_with_dropout_directional_derivative_and_determinism():
+    """With dropout on (hidden 0.1, attention 0.1) the masks cannot match torch's generator, so the whole-step check is a property:
+    for a FIXED dropout seed, noise and t the loss is a deterministic function of the parameters, and the hand-written backward
+    (which regenerates every mask) must give its directional derivative: (L(theta + e u) - L(theta - e u)) / 2e = <grad, u> for
+    u = grad / |grad|.  A backward mask that disagreed with the forward's would be off by O(p) = 10 %; the bar is 1 %."""
+    t, meta, w, tr, ctx, tgt = _trainer("train_tiny_plain", hidden_dropout=0.1, attention_dropout=0.1)
+    draws = noise_list(t, int(meta["n_noise"]))
+    kw = dict(draws=draws, t=t["t"], dropout_seed=1234)
+    a = tr.forward_backward(ctx, tgt, **kw)
+    b = tr.forward_backward(ctx, tgt, **kw)
+    assert float(a["loss"]) == float(b["loss"]) and all(torch.equal(a["grads"][k], b["grads"][k]) for k in a["grads"])
+    c = tr.forward_backward(ctx, tgt, draws=draws, t=t["t"], dropout_seed=99)
+    assert float(c["loss"]) != float(a["loss"])
+    _, _, _, plain, _, _ = _trainer("train_tiny_plain")
+    d = plain.forward_backward(ctx, tgt, draws=draws, t=t["t"])
+    assert abs(float(a["loss"]) - float(d["loss"])) > 1e-4, "dropout must change the forward"
+    flat = tr.flatten_gradients(a["grads"])[: tr._n_flat]
+    norm = float(flat.norm())
+    u = flat / norm
+    eps = 0.02
+    theta = tr._flat_p.clone()
+    vals = []
+    for sgn in (1.0, -1.0):
+        tr._flat_p.copy_(theta + sgn * eps * u)
+        tr.refresh_planes()
+        vals.append(float(tr.forward_backward(ctx, tgt, **kw)["loss"].double()))
+    tr._flat_p.copy_(theta)
+    tr.refresh_planes()
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    print(f"\n[dropout step] |grad| {norm:.5f}  finite difference {fd:.5f}  losses {vals}")
+    assert abs(fd - norm) <= 0.01 * norm

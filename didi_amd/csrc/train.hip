@@ -259,16 +259,25 @@ extern "C" int didi_colsum(const float* x, int M, int N, float* out, void* works
 
 // ------------------------------------------------------------------ transposing split: fp32 [R, C] -> planes [C, R]
 // 64 x 64 tiles through LDS (padded rows: conflict-free both ways); reads and writes are row-contiguous.
-__global__ void __launch_bounds__(256) transpose_split_kernel(const float* src, int R, int C, int ldo, u16* hi, u16* lo, int f16) {
+// `partial` (nullable): [gridDim.y][C] column sums of each 64-row block -- the bias gradient as a by-product of the pass that
+// prepares dC^T for the weight-gradient GEMM (a separate column-sum pass re-read the whole tensor: 3 ms per training step).
+__global__ void __launch_bounds__(256) transpose_split_kernel(const float* src, int R, int C, int ldo, u16* hi, u16* lo, int f16,
+                                                              float* partial) {
     __shared__ float tile[64][65];
+    __shared__ float red[4][64];
     if (f16) f16_saturate_mode();
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    float cs = 0.f;
     for (int i = ty; i < 64; i += 4) {
         const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+        const float val = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+        tile[i][tx] = val;
+        cs += val;
     }
+    if (partial) red[ty][tx] = cs;
     __syncthreads();
+    if (partial && ty == 0 && c0 + tx < C) partial[(size_t)blockIdx.y * C + c0 + tx] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
     for (int i = ty; i < 64; i += 4) {
         const int c = c0 + i, r = r0 + tx;  // output row c, output column r
         if (c < C && r < ldo) {
@@ -283,7 +292,23 @@ __global__ void __launch_bounds__(256) transpose_split_kernel(const float* src, 
 extern "C" int didi_transpose_split(const float* src, int R, int C, int ldo, uint16_t* hi, uint16_t* lo, int plane_format, void* stream) {
     DIDI_CHECK_ARG(src && hi && R > 0 && C > 0 && ldo >= R);
     DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
-    transpose_split_kernel<<<dim3(cdiv(C, 64), cdiv(ldo, 64)), 256, 0, as_stream(stream)>>>(src, R, C, ldo, hi, lo, plane_format == DIDI_FMT_FP16);
+    transpose_split_kernel<<<dim3(cdiv(C, 64), cdiv(ldo, 64)), 256, 0, as_stream(stream)>>>(src, R, C, ldo, hi, lo, plane_format == DIDI_FMT_FP16,
+                                                                                          nullptr);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+extern "C" size_t didi_transpose_split_colsum_bytes(int R, int C) { return R > 0 && C > 0 ? (size_t)cdiv((R + 7) / 8 * 8, 64) * C * sizeof(float) : 0; }
+
+extern "C" int didi_transpose_split_colsum(const float* src, int R, int C, int ldo, uint16_t* hi, uint16_t* lo, int plane_format, float* colsum,
+                                           void* workspace, void* stream) {
+    DIDI_CHECK_ARG(src && hi && colsum && workspace && R > 0 && C > 0 && ldo >= R && ldo == (R + 7) / 8 * 8);
+    DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
+    const int nb = cdiv(ldo, 64);
+    hipStream_t st = as_stream(stream);
+    transpose_split_kernel<<<dim3(cdiv(C, 64), nb), 256, 0, st>>>(src, R, C, ldo, hi, lo, plane_format == DIDI_FMT_FP16, reinterpret_cast<float*>(workspace));
+    DIDI_LAUNCH_CHECK();
+    partial_rows_sum_kernel<<<cdiv(C, 64), 256, 0, st>>>(reinterpret_cast<const float*>(workspace), nb, C, C, colsum, nullptr);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

@@ -311,9 +311,24 @@ def transpose_split(x, dtype=torch.bfloat16):
     return hi, lo
 
 
-def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True):
-    """Backward of C = A W^T + b (nn.Linear): dC [M,N], A [M,K], W [N,K] fp32 -> (dA [M,K], dW [N,K], db [N] or None).
-    dgrad and wgrad are didi_gemm launches on transposed operand planes; db is a column sum."""
+def transpose_split_colsum(x, dtype=torch.bfloat16):
+    """``transpose_split`` + the column sums of x from the same pass -> (hi, lo, colsum fp32 [C])."""
+    x = _f32c(x)
+    R, Cc = x.shape
+    ldo = (R + 7) // 8 * 8
+    hi = torch.empty((Cc, ldo), dtype=dtype, device=x.device)
+    lo = torch.empty_like(hi)
+    out = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.didi_transpose_split_colsum_bytes(R, Cc), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.didi_transpose_split_colsum(x.data_ptr(), R, Cc, ldo, hi.data_ptr(), lo.data_ptr(), _fmt(dtype), out.data_ptr(),
+                                               ws.data_ptr(), _lib.current_stream()), "transpose_split_colsum")
+    return hi, lo, out
+
+
+def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, residual=None):
+    """Backward of C = A W^T + b (nn.Linear): dC [M,N], A [M,K], W [N,K] fp32 -> (dA [M,K] (+ residual), dW [N,K], db [N] or None).
+    dgrad and wgrad are didi_gemm launches on transposed operand planes; db comes out of the pass that transposes dC.
+    ``residual`` fp32 [M,K]: added to dA in the dgrad GEMM's epilogue (the gradient of a skip connection joining there)."""
     pd = plane_dtype(precision)
     dC, A, W = _f32c(dC), _f32c(A), _f32c(W)
     M, N = dC.shape
@@ -325,13 +340,16 @@ def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True):
         z = torch.zeros((M, pad), dtype=torch.float32, device=dC.device)
         z[:, :N] = dC
         dc_hi, dc_lo = split(z, dtype=pd)
-    dA = gemm(dc_hi, dc_lo, wt_hi, wt_lo, precision=precision, out_f32=True, out_planes=False)[2] if need_dA else None
-    dct_hi, dct_lo = transpose_split(dC, dtype=pd)       # [N, M8]
+    dA = gemm(dc_hi, dc_lo, wt_hi, wt_lo, precision=precision, out_f32=True, out_planes=False, residual=residual)[2] if need_dA else None
+    if bias:
+        dct_hi, dct_lo, db = transpose_split_colsum(dC, dtype=pd)  # [N, M8] + the bias gradient
+    else:
+        (dct_hi, dct_lo), db = transpose_split(dC, dtype=pd), None
     at_hi, at_lo = transpose_split(A, dtype=pd)          # [K, M8]
     # wgrad: few output tiles, K = the batch's rows -> the split-K form wherever it applies
     use_small = lib.didi_gemm_small_workspace_bytes(N, K, dct_hi.shape[1], _prec(precision)) > 0
     _, _, dW = gemm(dct_hi, dct_lo, at_hi, at_lo, precision=precision, out_f32=True, out_planes=False, small=() if use_small else None)
-    return dA, dW, (colsum(dC) if bias else None)
+    return dA, dW, db
 
 
 def act_backward(act, dy, saved):

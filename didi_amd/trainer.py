@@ -155,8 +155,8 @@ class DiDiTrainer:
     def _linear(self, w, a_hi, a_lo, **kw):
         return ops.gemm(a_hi, a_lo, w.hi, w.lo, bias=w.b, precision=self.precision, out_f32=True, **kw)
 
-    def _linear_bwd(self, dC, A, w):
-        return ops.linear_backward(dC, A, w.w, precision=self.precision)
+    def _linear_bwd(self, dC, A, w, residual=None):
+        return ops.linear_backward(dC, A, w.w, precision=self.precision, residual=residual)
 
     @torch.no_grad()
     def forward_backward(self, raw_context, target, *, draws=None, t=None, keep=False, dropout_seed=None):
@@ -319,7 +319,8 @@ class DiDiTrainer:
         if d_hat_ce is not None:
             ops.axpby(1.0, d_hat_ce, 1.0, dh)
         d_x0_hat = dh.clone() if keep else None
-        dctx = torch.zeros((B * Cn, H), dtype=torch.float32, device=dev) if cfg.has_adapter else None
+        dctx = None  # gradient of the context (adapter output): summed over the layers' cross-attention K/V projections
+        need_dctx = cfg.has_adapter
         for li in reversed(range(cfg.dec_layers)):
             L, ln, s = self._lin[li], self._layer_names[li], saved[li]
 
@@ -331,9 +332,8 @@ class DiDiTrainer:
             df, dW, dbias = self._linear_bwd(drop(ds3, None, s["off_down"]) if ph > 0 else ds3, s["f"], L["down"])
             put(ln["down"], dW, dbias)
             du = ops.act_backward("gelu", df, s["u"])
-            dh2, dW, dbias = self._linear_bwd(du, s["h2"], L["up"])
+            dh2, dW, dbias = self._linear_bwd(du, s["h2"], L["up"], residual=ds3)  # + the skip connection around the FFN
             put(ln["up"], dW, dbias)
-            ops.axpby(1.0, ds3, 1.0, dh2)
             ds2, dg, db = ops.layernorm_backward(dh2, s["s2"], P[ln["ln2"] + ".weight"], eps)
             put(ln["ln2"], dg, db)
             dcatt, dW, dbias = self._linear_bwd(drop(ds2, None, s["off_co"]) if ph > 0 else ds2, s["catt"], L["co"])
@@ -343,14 +343,13 @@ class DiDiTrainer:
             dcq = torch.empty((B, S, H), dtype=torch.float32, device=dev)
             ops.attention_backward(s["cq"].view(B, S, H), ckv[:, :, :H], ckv[:, :, H:], dcatt.view(B, S, H), A, causal=False, key_mask=mask32,
                                    out=(dcq, dckv[:, :, :H], dckv[:, :, H:]), drop_p=pa, seed=dseed, offset=s["off_ca"])
-            dh1, dW, dbias = self._linear_bwd(dcq.view(M, H), s["h1"], L["cq"])
+            dh1, dW, dbias = self._linear_bwd(dcq.view(M, H), s["h1"], L["cq"], residual=ds2)
             put(ln["cq"], dW, dbias)
-            ops.axpby(1.0, ds2, 1.0, dh1)
-            dctx_l, dW, dbias = self._linear_bwd(dckv.view(B * Cn, 2 * H), ctx.view(B * Cn, H), L["ckv"])
+            dctx_l, dW, dbias = self._linear_bwd(dckv.view(B * Cn, 2 * H), ctx.view(B * Cn, H), L["ckv"], residual=dctx)
             put(ln["ck"], dW[:H].contiguous(), dbias[:H].contiguous())
             put(ln["cv"], dW[H:].contiguous(), dbias[H:].contiguous())
-            if dctx is not None:
-                ops.axpby(1.0, dctx_l, 1.0, dctx)
+            if need_dctx:
+                dctx = dctx_l  # accumulated over the layers in the dgrad epilogue
             ds1, dg, db = ops.layernorm_backward(dh1, s["s1"], P[ln["ln1"] + ".weight"], eps)
             put(ln["ln1"], dg, db)
             datt, dW, dbias = self._linear_bwd(drop(ds1, None, s["off_o"]) if ph > 0 else ds1, s["att"], L["o"])
@@ -359,10 +358,9 @@ class DiDiTrainer:
             dqkv = torch.empty_like(qkv)
             ops.attention_backward(qkv[:, :, :H], qkv[:, :, H:2 * H], qkv[:, :, 2 * H:], datt.view(B, S, H), A, causal=True,
                                    out=(dqkv[:, :, :H], dqkv[:, :, H:2 * H], dqkv[:, :, 2 * H:]), drop_p=pa, seed=dseed, offset=s["off_sa"])
-            dh0, dW, dbias = self._linear_bwd(dqkv.view(M, 3 * H), s["h0"], L["qkv"])
+            dh0, dW, dbias = self._linear_bwd(dqkv.view(M, 3 * H), s["h0"], L["qkv"], residual=ds1)
             for j, key in enumerate(("q", "k", "v")):
                 put(ln[key], dW[j * H:(j + 1) * H].contiguous(), dbias[j * H:(j + 1) * H].contiguous())
-            ops.axpby(1.0, ds1, 1.0, dh0)
             dh = dh0
             saved[li] = None  # free this layer's activations
         # decoder embeddings

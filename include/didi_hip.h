@@ -495,6 +495,11 @@ size_t didi_colsum_bytes(int M, int N);
 int didi_colsum(const float* x, int M, int N, float* out, void* workspace, void* stream);
 /* fp32 src [R, C] -> split planes of its transpose [C, ldo], ldo >= R (columns R..ldo-1 zero: pads the GEMM's K to % 8). */
 int didi_transpose_split(const float* src, int R, int C, int ldo, uint16_t* hi, uint16_t* lo, int plane_format, void* stream);
+/* The same pass with the column sums of src as a by-product (out[c] = sum_r src[r, c]: the bias gradient while dC^T is being
+ * prepared for the weight-gradient GEMM).  ldo == R rounded up to 8; workspace of didi_transpose_split_colsum_bytes(R, C). */
+size_t didi_transpose_split_colsum_bytes(int R, int C);
+int didi_transpose_split_colsum(const float* src, int R, int C, int ldo, uint16_t* hi, uint16_t* lo, int plane_format, float* colsum,
+                                void* workspace, void* stream);
 
 /* y = act(x) (fp32, nullable) + its split planes (nullable): the training forward keeps the pre-activation, so GELU is its own
  * pass there.  dx = dy * act'(.) for the two activations on the trained path: DIDI_ACT_GELU takes the PRE-activation (BertIntermediate,

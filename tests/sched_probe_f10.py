@@ -53,6 +53,9 @@ def main():
         for tail in (((0, "fp16x3"), (0, "fp16x2")), ((32, "fp16x3"), (100, "fp16x2")), ((64, "fp16x3"), (150, "fp16x2")),
                      ((128, "fp16x3"), (201, "fp16x2")), ((32, "fp16x3"), (0, "fp16x2")), ((64, "fp16x3"), (0, "fp16x2"))):
             cands.append(("fp16-sched", sched, tail))
+    t64 = ((64, "fp16x3"),)
+    cands += [("fp16-sched", ((0, "fp16x2"),), t64), ("fp16-sched", ((0.7, "fp16"), (0, "fp16x2")), t64),
+              ("fp16-sched", ((0.5, "fp16"), (0, "fp16x2")), t64), ("fp16-sched", ((0.35, "fp16"), (0, "fp16x2")), t64), ("fp16", None, None)]
     for precision, sched, tail in cands:
         model = DiDiSampler(sd, cfg, device="cuda", precision=precision, schedule=sched, tail_calls=tail)
         trace = []

@@ -332,7 +332,7 @@ def main():
     n_calls = plan.n_calls
     # precision of every call (a precision schedule has up to three regimes); one representative call per regime is instrumented
     names = {v: k for k, v in __import__("didi_amd.ops", fromlist=["PRECISIONS"]).PRECISIONS.items()}
-    per_call = model.call_precisions(plan.time_row) or [model.prec] * n_calls
+    per_call = model.call_precisions(plan.time_row, args.mode) or [model.prec] * n_calls
     regimes = []  # (precision name, number of calls, index of its middle call)
     for pv in dict.fromkeys(per_call):
         idx = [k for k, q in enumerate(per_call) if q == pv]
@@ -440,7 +440,8 @@ def main():
             "global_batch": B_total, "seq_len": S, "denoiser_calls": n_calls, "parallelism": f"dp{world} (batch shard, id all-gather)",
             "weights": "random-init N(0,0.02), seed 1234", "noise": "in-kernel Philox",
             "precision": args.precision,
-            "precision_schedule": ({"timestep_thresholds": [list(x) for x in model.schedule], "calls": {r[0]: r[1] for r in regimes}}
+            "precision_schedule": ({"timestep_thresholds": [list(x) for x in (model.schedule_euler if args.mode == "euler" else model.schedule)],
+                                    "tail_calls": [list(x) for x in model.tail_calls], "calls": {r[0]: r[1] for r in regimes}}
                                    if model.schedule else None),
             "precision_note": {
                 "fp16-sched": ("fp16 operand planes where BASELINE configs[1] says bf16: 16-bit MFMA operands with fp32 accumulation either way; the "

@@ -26,7 +26,7 @@ ERR_FAULT = -5
 FAULT_LN_EXCHANGE, FAULT_FP16_RANGE = 1, 2
 ABI_VERSION = 4
 # didi_set_option keys (tuning switches for A/B runs; defaults = production path)
-OPTIONS = {"GEMM_LN": 0, "GEMM_SMALL": 1, "GEMM_BIG": 2, "GEMM_PP": 3, "GEMM_MT": 4, "BIG_MIN_M": 5, "SMALL_MAX_M": 6}
+OPTIONS = {"GEMM_LN": 0, "GEMM_SMALL": 1, "GEMM_BIG": 2, "GEMM_PP": 3, "GEMM_MT": 4, "BIG_MIN_M": 5, "SMALL_MAX_M": 6, "X2_GEMMS": 7}
 
 
 class StepArgs(C.Structure):

@@ -135,12 +135,13 @@ int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi
 
 // ------------------------------------------------------------------ tuning switches (didi_set_option)
 static int g_options[DIDI_OPT_COUNT] = {/*GEMM_LN*/ 1, /*GEMM_SMALL*/ 1, /*GEMM_BIG*/ 1, /*GEMM_PP*/ 1, /*GEMM_MT*/ 4,
-                                        /*BIG_MIN_M*/ 2048, /*SMALL_MAX_M*/ 2048};
+                                        /*BIG_MIN_M*/ 2048, /*SMALL_MAX_M*/ 2048, /*X2_GEMMS*/ 63};
 int didi_opt(int key) { return g_options[key]; }
 extern "C" int didi_set_option(int key, int value) {
     DIDI_CHECK_ARG(key >= 0 && key < DIDI_OPT_COUNT);
     if (key == DIDI_OPT_GEMM_MT) DIDI_CHECK_ARG(value == 2 || value == 4);
     if (key == DIDI_OPT_BIG_MIN_M || key == DIDI_OPT_SMALL_MAX_M) DIDI_CHECK_ARG(value >= 0);
+    if (key == DIDI_OPT_X2_GEMMS) DIDI_CHECK_ARG(value >= 0 && value <= 63);
     g_options[key] = value;
     return DIDI_OK;
 }
@@ -215,7 +216,9 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
     const bool f16 = prec == DIDI_PREC_FP16 || prec == DIDI_PREC_FP16X2 || prec == DIDI_PREC_FP16X3;
     const int fmt = f16 ? DIDI_FMT_FP16 : DIDI_FMT_BF16;
     const int attn_prec = prec == DIDI_PREC_FP16X2 ? DIDI_PREC_FP16 : prec;
-    const int proj_prec = prec;
+    // FP16X2 calls: which GEMMs multiply the weights' remainder (DIDI_OPT_X2_GEMMS); the planes are the same either way
+    const int x2_mask = didi_opt(DIDI_OPT_X2_GEMMS);
+    auto pc = [&](int cls) { return prec == DIDI_PREC_FP16X2 && !((x2_mask >> cls) & 1) ? (int)DIDI_PREC_FP16 : prec; };
     const bool ffn_lo = x3;
     const size_t Mc = (size_t)a->B * a->C;
     Prof prof{a->prof_events_host, a->prof_capacity, 0};
@@ -235,7 +238,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         const didi_decoder_layer& ly = dec->layers_host[l];
         const bool last = l == dec->L - 1;
         // --- causal self-attention block
-        TRY(gemm(ly.qkv, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, w.qkv_hi,
+        TRY(gemm(ly.qkv, pc(0), M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, w.qkv_hi,
                  x3 ? w.qkv_lo : nullptr, 3 * H, stream, &prof, w.small_ws, a->fault));
         didi_attn_args at{};
         at.B = a->B; at.heads = dec->heads; at.Sq = a->S; at.Sk = a->S; at.D = D; at.precision = attn_prec;
@@ -245,26 +248,26 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.V_hi = w.qkv_hi + 2 * H; at.V_lo = x3 ? w.qkv_lo + 2 * H : nullptr; at.ldv = 3 * H;
         at.O_hi = w.att_hi; at.O_lo = x3 ? w.att_lo : nullptr; at.ldo = H;
         TRY(didi_attention(&at, stream));
-        TRY(gemm_ln(ly.attn_out, proj_prec, fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln1_g, ly.ln1_b,
+        TRY(gemm_ln(ly.attn_out, pc(1), fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln1_g, ly.ln1_b,
                     dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault));
         // --- cross-attention block (K/V hoisted: didi_decoder_prepare_context)
         u16* q_hi = w.qkv_hi;
         u16* q_lo = x3 ? w.qkv_lo : nullptr;
-        TRY(gemm(ly.cq, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream, &prof, w.small_ws, a->fault));
+        TRY(gemm(ly.cq, pc(2), M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream, &prof, w.small_ws, a->fault));
         const size_t kvoff = (size_t)l * Mc * 2 * H;
         at.Sk = a->C; at.causal = 0; at.key_mask = a->ctx_mask; at.key_count = a->ctx_count;
         at.Q_hi = q_hi; at.Q_lo = q_lo; at.ldq = H;
         at.K_hi = a->kv_hi + kvoff; at.K_lo = x3 ? a->kv_lo + kvoff : nullptr; at.ldk = 2 * H;
         at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;
         TRY(didi_attention(&at, stream));
-        TRY(gemm_ln(ly.cross_out, proj_prec, fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln2_g, ly.ln2_b,
+        TRY(gemm_ln(ly.cross_out, pc(3), fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln2_g, ly.ln2_b,
                     dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault));
         // --- feed-forward block
-        TRY(gemm(ly.ffn_up, prec, M, w.h_hi, w.h_lo, H, DIDI_ACT_GELU, nullptr, nullptr, 0, nullptr, w.ffn_hi,
+        TRY(gemm(ly.ffn_up, pc(4), M, w.h_hi, w.h_lo, H, DIDI_ACT_GELU, nullptr, nullptr, 0, nullptr, w.ffn_hi,
                  ffn_lo ? w.ffn_lo : nullptr, I, stream, &prof, w.small_ws, a->fault));
         u16* o_hi = last && a->x0_hi ? a->x0_hi : w.h_hi;
         u16* o_lo = last && a->x0_hi ? a->x0_lo : w.h_lo;
-        TRY(gemm_ln(ly.ffn_down, prec, fmt, M, w.ffn_hi, w.ffn_lo, I, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln3_g, ly.ln3_b,
+        TRY(gemm_ln(ly.ffn_down, pc(5), fmt, M, w.ffn_hi, w.ffn_lo, I, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln3_g, ly.ln3_b,
                     dec->ln_eps, o_hi, o_lo, last ? a->x0_f32 : nullptr, stream, &prof, w.small_ws, a->fault));
     }
     if (a->prof_used_host) *a->prof_used_host = prof.used;

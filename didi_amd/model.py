@@ -27,6 +27,11 @@ from .schedule import configure_schedule
 # T = 2000, sqrt schedule: t > 700 / t > 128 / the rest): one product while the input is mostly fresh noise, the weights'
 # remainder once x_t starts to carry the previous estimate, all three products for the last steps.
 DEFAULT_SCHEDULE = ((0.35, "fp16"), (0.064, "fp16x2"), (0, "fp16x3"))
+# The euler sampler integrates an ODE: an error made at a high timestep shifts the trajectory for good instead of being drowned
+# by the next step's fresh noise as in ddpm (T = 2000, f = 10, final x_t: 2.7e-4 with the ddpm schedule whatever the tail, 4.2e-5
+# without a one-product regime; ids 4 vs 1 of 2048 on held-out seeds: profiles/r02_sched_probe_f10_euler.log,
+# r02_parity_heldout_f10_euler.log).  So euler loops get no one-product regime.
+DEFAULT_SCHEDULE_EULER = ((0.064, "fp16x2"), (0, "fp16x3"))
 # The loop forgets an earlier error per CALL, not per unit of t: with step_freq > 1 the timestep thresholds leave too few calls
 # in the precise regime (T = 2000, f = 10: 13 calls of fp16x3 -> the final x_t is 4.6e-4 off and 4 of 2048 ids differ; with 32
 # calls 6.5e-5 / 0, with 64 calls 8e-6 / 0: tests/sched_probe_f10.py, profiles/r02_sched_probe_f10_ddpm.log).  Floors applied
@@ -84,12 +89,14 @@ class DiDiSampler:
         the last pair must have t_above = 0.  Needs an fp16-plane ``precision``.
         ``tail_calls``: (calls_from_the_end, precision) floors on top of the schedule: the last n calls of a loop run at least
         that precision ("fp16-sched" defaults to ``DEFAULT_TAIL_CALLS``; an explicit schedule to none)."""
+        schedule_euler = None
         if precision == "fp16-sched":
+            schedule_euler = None if schedule else DEFAULT_SCHEDULE_EULER  # an explicit schedule is used for both samplers
             precision, schedule = "fp16x2", (schedule or DEFAULT_SCHEDULE)
             tail_calls = DEFAULT_TAIL_CALLS if tail_calls is None else tail_calls
         if precision not in ("bf16", "fp16", "fp16x2", "bf16x3"):
             raise ValueError("precision must be one of bf16, fp16, fp16x2, bf16x3, fp16-sched")
-        if schedule is not None:  # thresholds below 1 are fractions of T
+        def resolve(schedule):  # thresholds below 1 are fractions of T
             resolved = []
             for t, p in schedule:
                 frac = 0 < t < 1
@@ -103,8 +110,15 @@ class DiDiSampler:
             ok = ok and schedule[-1][0] == 0 and all(a[0] > b[0] for a, b in zip(schedule, schedule[1:]))
             if not ok:
                 raise ValueError("a precision schedule needs fp16-plane precisions and (t_above, precision) pairs in decreasing t ending at 0")
+            return schedule
+
+        if schedule is not None:
+            schedule = resolve(schedule)
+        if schedule_euler is not None:
+            schedule_euler = resolve(schedule_euler)
         self.cfg, self.device, self.precision = cfg, torch.device(device), precision
         self.schedule = schedule
+        self.schedule_euler = schedule_euler if schedule_euler is not None else schedule  # "fp16-sched": DEFAULT_SCHEDULE_EULER
         self.tail_calls = tuple(tail_calls or ())  # an explicit schedule is taken as written unless floors are given too
         if self.tail_calls and (not schedule or any(p not in _RANK or n < 0 for n, p in self.tail_calls)):
             raise ValueError("tail_calls = (calls_from_the_end, fp16|fp16x2|fp16x3) pairs, and only together with a schedule")
@@ -345,11 +359,13 @@ class DiDiSampler:
         all three products there (once per batch), as the engine's final rounding does."""
         return "fp16x3" if self.precision == "fp16x2" or self.schedule else self.precision
 
-    def call_precisions(self, time_rows):
-        """C-ABI precision of every denoiser call of a loop, from the timestep (time-embedding row) of each; None = uniform."""
+    def call_precisions(self, time_rows, mode="ddpm"):
+        """C-ABI precision of every denoiser call of a loop, from the timestep (time-embedding row) of each and the sampler
+        (``mode`` "euler" reads ``schedule_euler``); None = uniform."""
         if not self.schedule:
             return None
-        names = [next(p for t_above, p in self.schedule if t > t_above) for t in time_rows]
+        sched = self.schedule_euler if mode == "euler" else self.schedule
+        names = [next(p for t_above, p in sched if t > t_above) for t in time_rows]
         n = len(names)
         for k in range(n):
             from_end = n - 1 - k

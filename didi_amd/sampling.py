@@ -134,7 +134,7 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
         if clamp:
             a.clamp_emb = model.emb.weight.data_ptr()
         a.fault = b["fault"].data_ptr()
-        precs = model.call_precisions(plan.time_row)
+        precs = model.call_precisions(plan.time_row, mode)
         prec_arr = (C.c_int * n_calls)(*precs) if precs is not None else None  # kept alive until the call returns
         a.precision_host = prec_arr if prec_arr is not None else C.cast(None, C.POINTER(C.c_int))
         if _prof is not None:  # bench.py: HIP events around the GEMM launches of chosen denoiser calls
@@ -174,7 +174,7 @@ def _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp=False):
         x0.copy_(ops.embed_gather(ids.view(B, S), model.emb.weight))
     noise = torch.randn((B, S, H), dtype=torch.float32, device=dev)  # sampling.py:13
 
-    precs = model.call_precisions(plan.time_row)
+    precs = model.call_precisions(plan.time_row, mode)
 
     def forward(step_kw, t, k):
         fa = _lib.ForwardArgs()

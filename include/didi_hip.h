@@ -71,7 +71,10 @@ enum {
     DIDI_OPT_GEMM_MT = 4,      /* 4 (default) or 2: 64-row wave tiles along M of the in-phase big tile */
     DIDI_OPT_BIG_MIN_M = 5,    /* default 2048 */
     DIDI_OPT_SMALL_MAX_M = 6,  /* default 2048 */
-    DIDI_OPT_COUNT = 7
+    DIDI_OPT_X2_GEMMS = 7,     /* bit mask of the decoder GEMMs that multiply the weights' remainder plane in an FP16X2 call: bit 0 qkv,
+                                  1 attention output, 2 cross-attention query, 3 cross-attention output, 4 FFN up, 5 FFN down; the others
+                                  run one product there.  Default 63 (all) */
+    DIDI_OPT_COUNT = 8
 };
 int didi_set_option(int key, int value);
 int didi_get_option(int key, int* value);

@@ -354,6 +354,11 @@ def test_precision_schedule(name):
     sched.schedule = ((700, "fp16"), (128, "fp16x2"), (0, "fp16x3"))  # the default's thresholds at T = 2000
     precs = sched.call_precisions(rows)
     assert precs.count(5) == 64 and all(p == 5 for p in precs[-64:]) and precs.count(2) == 130 and precs.count(4) == 7
+    # euler integrates an ODE (errors persist): its default schedule has no one-product regime; an explicit schedule serves both
+    sched.schedule_euler = ((128, "fp16x2"), (0, "fp16x3"))
+    precs = sched.call_precisions(rows, "euler")
+    assert precs.count(2) == 0 and precs.count(5) == 64 and precs.count(4) == 137
+    assert part.schedule_euler == part.schedule and part.call_precisions(plan.time_row, "euler") == part.call_precisions(plan.time_row)
     floor = DiDiSampler(w, cfg, device="cuda", precision="fp16x2", schedule=((0, "fp16x2"),), tail_calls=((1, "fp16x3"),))
     precs = floor.call_precisions(plan.time_row)
     assert precs[-1] == 5 and all(p == 4 for p in precs[:-1])

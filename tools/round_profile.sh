@@ -18,3 +18,9 @@ for P in fp16 fp16x2 fp16x3; do
   python3 tools/pmc_traffic.py $(find $O/${TAG}_pmc_${P}_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/${TAG}_pmc_${P}_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/gemm_traffic_${P}.json
   rm -rf $O/${TAG}_pmc_${P}_FETCH_SIZE $O/${TAG}_pmc_${P}_WRITE_SIZE
 done
+# the other BASELINE configurations as bench lines (single GPU): configs[2] at its per-GPU shape, configs[3] shortened to T = 100
+# (x 20 for T = 2000), configs[4] = the training step
+timeout -k 10 300 python3 bench.py --preset configs2 --no-cpu-baseline > $O/${TAG}_bench_configs2.log 2>&1
+timeout -k 10 400 python3 bench.py --preset configs3 --diffusion-steps 100 --steps 1 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_configs3_T100.log 2>&1
+timeout -k 10 400 python3 bench.py --preset configs4 --steps 5 --warmup 2 > $O/${TAG}_bench_configs4.log 2>&1
+tail -c 300 $O/${TAG}_bench_configs2.log; echo; tail -c 300 $O/${TAG}_bench_configs4.log; echo

@@ -37,7 +37,7 @@ T0 = time.time()
 
 def main():
     from didi_amd.config import DiDiConfig
-    from didi_amd.model import DEFAULT_SCHEDULE, DiDiSampler
+    from didi_amd.model import DEFAULT_SCHEDULE, DEFAULT_SCHEDULE_EULER, DiDiSampler
     from didi_amd.sampling import sample
     from didi_amd.synthetic import RawContext, synthetic_batch, synthetic_state_dict
 
@@ -49,6 +49,10 @@ def main():
     sw, sb, sn = (int(x) for x in os.environ.get("PROBE_SEEDS", "1234,11,21").split(","))
     print(f"seeds: weights {sw}, batch {sb}, noise {sn}", flush=True)
     sd = synthetic_state_dict(cfg, seed=sw)
+    if os.environ.get("PROBE_TRAINED_LIKE"):  # outlier features, spread LayerNorm gammas, x4 attention / FFN weights (tests/test_gpu_precision.py)
+        from test_gpu_precision import _trained_like
+        sd = _trained_like(sd)
+        print("weights: trained-like statistics", flush=True)
     ids, mask = synthetic_batch(B, C, cfg.vocab, seed=sb)
     n_calls = len(range(cfg.diffusion_steps, 1, -f)) + 1
     n_draws = n_calls if mode == "ddpm" else n_calls + 1
@@ -67,7 +71,7 @@ def main():
     configs = [
         ("bf16x3", dict(precision="bf16x3")),
         sched((0, "fp16x3")),
-        ("fp16-sched (default) " + str(DEFAULT_SCHEDULE), dict(precision="fp16-sched")),
+        ("fp16-sched (default) " + str(DEFAULT_SCHEDULE_EULER if mode == "euler" else DEFAULT_SCHEDULE), dict(precision="fp16-sched")),
         sched((1000, "fp16"), (128, "fp16x2"), (0, "fp16x3")),
         sched((600, "fp16"), (0, "fp16x3")),
         ("fp16x2", dict(precision="fp16x2")),

@@ -213,7 +213,7 @@ def main_training(args):
             "workload": (f"BASELINE configs[4] (training step): blenderbot-400M-distill-sized frozen encoder + BertConfig-default decoder "
                          f"(12x768/12h/3072), V={cfg.vocab}, T={cfg.diffusion_steps}, batch {B}/GPU, context {S}, target {S}, AdamW + linear LR + clip 1.0, "
                          f"decoder dropout 0.1 / 0.1 (configs/train.yaml:22-23)"),
-            "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world} (bucketed gradient all-reduce + 5 metric scalars in the last bucket)",
+            "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world} (gradient all-reduce in 57 MB buckets launched under the backward; the 5 metric scalars in the buffer's tail)",
             "trainable_parameters": n_params, "precision": args.train_precision,
             "world_size_seen": torch.distributed.get_world_size() if world > 1 else 1,
             "backend": torch.distributed.get_backend() if world > 1 else None,

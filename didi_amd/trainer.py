@@ -155,16 +155,18 @@ class DiDiTrainer:
     def _linear(self, w, a_hi, a_lo, **kw):
         return ops.gemm(a_hi, a_lo, w.hi, w.lo, bias=w.b, precision=self.precision, out_f32=True, **kw)
 
-    def _linear_bwd(self, dC, A, w, residual=None):
-        return ops.linear_backward(dC, A, w.w, precision=self.precision, residual=residual)
+    def _linear_bwd(self, dC, A, w, residual=None, need_dA=True):
+        return ops.linear_backward(dC, A, w.w, precision=self.precision, residual=residual, need_dA=need_dA)
 
     @torch.no_grad()
-    def forward_backward(self, raw_context, target, *, draws=None, t=None, keep=False, dropout_seed=None):
+    def forward_backward(self, raw_context, target, *, draws=None, t=None, keep=False, dropout_seed=None, grad_sink=None):
         """One ``training_step`` and its backward -> dict(mse, ce, t_T, loss, ce_hat [0-dim device tensors], grads {name: fp32}).
 
         ``draws`` / ``t``: injected normal draws [n0, n1] and timesteps (parity tests), else Philox noise / ``torch.randint`` as
         the reference draws them.  ``keep``: also return the tensors the tests compare (x_0, x_t, x_0_hat, d x_0_hat).
-        ``dropout_seed``: key of the step's dropout masks (default: drawn from torch's global generator)."""
+        ``dropout_seed``: key of the step's dropout masks (default: drawn from torch's global generator).
+        ``grad_sink``: an ``_OverlappedReducer``: told after every decoder layer's backward (and at the end) which gradients exist,
+        so that their all-reduce runs under the rest of the backward; the gradients it receives still carry the loss scale."""
         cfg, dev, P = self.cfg, self.device, self.params
         ids, tmask = target.input_ids.to(dev), target.attention_mask.to(dev)
         cids, cmask = raw_context.input_ids.to(dev), raw_context.attention_mask.to(dev)
@@ -345,7 +347,7 @@ class DiDiTrainer:
                                    out=(dcq, dckv[:, :, :H], dckv[:, :, H:]), drop_p=pa, seed=dseed, offset=s["off_ca"])
             dh1, dW, dbias = self._linear_bwd(dcq.view(M, H), s["h1"], L["cq"], residual=ds2)
             put(ln["cq"], dW, dbias)
-            dctx_l, dW, dbias = self._linear_bwd(dckv.view(B * Cn, 2 * H), ctx.view(B * Cn, H), L["ckv"], residual=dctx)
+            dctx_l, dW, dbias = self._linear_bwd(dckv.view(B * Cn, 2 * H), ctx.view(B * Cn, H), L["ckv"], residual=dctx, need_dA=need_dctx)
             put(ln["ck"], dW[:H].contiguous(), dbias[:H].contiguous())
             put(ln["cv"], dW[H:].contiguous(), dbias[H:].contiguous())
             if need_dctx:
@@ -363,6 +365,8 @@ class DiDiTrainer:
                 put(ln[key], dW[j * H:(j + 1) * H].contiguous(), dbias[j * H:(j + 1) * H].contiguous())
             dh = dh0
             saved[li] = None  # free this layer's activations
+            if grad_sink is not None:
+                grad_sink.layer_done(li, G)
         # decoder embeddings
         if ph > 0:
             dh = drop(dh, None, off_emb)
@@ -394,7 +398,9 @@ class DiDiTrainer:
             dpre = ops.act_backward("tanh", dz, z)
             _, dW, dbias = ops.linear_backward(dpre, enc, self._ad0.w, precision=self.precision, need_dA=False)
             G["adapter.0.weight"], G["adapter.0.bias"] = dW, dbias
-        if ls != 1.0:
+        if grad_sink is not None:
+            grad_sink.finish(G, ls)
+        elif ls != 1.0:
             for g_ in G.values():
                 ops.axpby(0.0, g_, 1.0 / ls, g_)
         out = dict(mse=mse, ce=ce, t_T=t_T, loss=loss, ce_hat=ce_hat, grads=G, t=t)
@@ -457,15 +463,102 @@ class DiDiTrainer:
         self.refresh_planes()
         return norm
 
-    def training_step(self, raw_context, target, world=1, **kw):
+    def training_step(self, raw_context, target, world=1, overlap=True, **kw):
         """forward + backward + (``world`` > 1: bucketed gradient all-reduce over the default process group with the five logged
-        scalars folded into the last bucket, src/training.py:37 + model.py:241-242) + clip + AdamW -> the step's dict with
-        ``metrics`` (fp32 [5]: mse, ce, t_T, loss, ce_hat, averaged over ranks) and ``grad_norm``."""
+        scalars in the flat buffer's tail, src/training.py:37 + model.py:241-242) + clip + AdamW -> the step's dict with
+        ``metrics`` (fp32 [5]: mse, ce, t_T, loss, ce_hat, averaged over ranks) and ``grad_norm``.
+        ``overlap``: launch each bucket's all-reduce as soon as its layers' backward is done (what DDP does), on RCCL's own
+        stream under the remaining backward; False = one pass over the buckets after the backward."""
         from .training import metric_message
 
-        out = self.forward_backward(raw_context, target, **kw)
-        flat = self.flatten_gradients(out["grads"], metric_message(out))
-        self.allreduce_flat(flat, world)
+        if world > 1 and overlap:
+            sink = _OverlappedReducer(self, world)
+            out = self.forward_backward(raw_context, target, grad_sink=sink, **kw)
+            flat = sink.flat
+            flat[self._n_flat: self._n_flat + 5] = metric_message(out) / world  # the tail's own small all-reduce (5 floats)
+            sink.reduce_tail()
+        else:
+            out = self.forward_backward(raw_context, target, **kw)
+            flat = self.flatten_gradients(out["grads"], metric_message(out))
+            self.allreduce_flat(flat, world)
         out["grad_norm"] = self.optimizer_step(flat)
         out["metrics"] = flat[self._n_flat: self._n_flat + 5].clone()
         return out
+
+
+def layer_buckets(layer_ranges, n_flat, layers_per_bucket=2):
+    """Bucket plan of the overlapped reduction.  ``layer_ranges``: [(start, end)] of each decoder layer's slice of the flat buffer
+    (ascending, contiguous); the backward finishes layers from the LAST to the first.  -> (buckets, head): ``buckets[j]`` =
+    (first_layer, start, end) is launched once layer ``first_layer`` is done and covers ``layers_per_bucket`` layers (the group
+    containing layer 0 may be smaller); ``head`` = (0, start_of_layer_0) holds everything that precedes the layers (embeddings,
+    classifier, adapter), reduced last.  The slices tile [0, n_flat) exactly."""
+    L = len(layer_ranges)
+    assert all(a[1] == b[0] for a, b in zip(layer_ranges, layer_ranges[1:])) and layer_ranges[-1][1] == n_flat
+    buckets = []
+    hi = L
+    while hi > 0:
+        lo = max(0, hi - layers_per_bucket)
+        buckets.append((lo, layer_ranges[lo][0], layer_ranges[hi - 1][1]))
+        hi = lo
+    return buckets, (0, layer_ranges[0][0])
+
+
+class _OverlappedReducer:
+    """Gradient all-reduce under the backward (what DDP's bucketed reducer does, src/training.py:37).  The flat gradient buffer
+    exists from the start of the backward; when the last layer of a bucket (two decoder layers = 57 MB at BERT-base width: xGMI
+    ring steps are per-link bound, so few large messages) has its gradients, they are copied into their slice and ONE
+    ``all_reduce(async_op=True)`` is enqueued: RCCL runs it on its own stream after the copies, the backward of the earlier
+    layers goes on.  The head of the buffer (embeddings, classifier, adapter: produced last) follows at the end, and the
+    optimiser waits on every handle.  Averaging (and the fp16 modes' loss scale) is one scaling of the flat buffer afterwards."""
+
+    def __init__(self, trainer, world, all_reduce=None):
+        import torch.distributed as tdist
+
+        self.tr, self.world = trainer, world
+        self.flat = torch.zeros(trainer._n_flat + trainer.METRIC_SLOTS, dtype=torch.float32, device=trainer.device)
+        self._all_reduce = all_reduce or (lambda t_: tdist.all_reduce(t_, op=tdist.ReduceOp.SUM, async_op=True))
+        ranges = []
+        for ln in trainer._layer_names:
+            offs = [trainer._offsets[v + sfx] for v in ln.values() for sfx in (".weight", ".bias")]
+            ends = [trainer._offsets[v + sfx] + (trainer.params[v + sfx].numel() + 3) // 4 * 4 for v in ln.values() for sfx in (".weight", ".bias")]
+            ranges.append((min(offs), max(ends)))
+        self.buckets, self.head = layer_buckets(ranges, trainer._n_flat)
+        self._launch_at = {b[0]: b for b in self.buckets}
+        self._layer_keys = [[v + sfx for v in ln.values() for sfx in (".weight", ".bias")] for ln in trainer._layer_names]
+        self._copied = set()
+        self.works = []
+
+    def _copy(self, keys, G):
+        dst, src = [], []
+        for k in keys:
+            off = self.tr._offsets[k]
+            dst.append(self.flat[off: off + G[k].numel()].view(G[k].shape))
+            src.append(G[k])
+        torch._foreach_copy_(dst, src)
+        self._copied.update(keys)
+
+    def layer_done(self, li, G):
+        self._copy(self._layer_keys[li], G)
+        b = self._launch_at.get(li)
+        if b is not None:
+            self.works.append(self._all_reduce(self.flat[b[1]: b[2]]))
+
+    def finish(self, G, loss_scale):
+        rest = [k for k in self.tr._offsets if k not in self._copied]
+        self._copy(rest, G)
+        if self.head[1] > self.head[0]:
+            self.works.append(self._all_reduce(self.flat[self.head[0]: self.head[1]]))
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        self.works = []
+        n = self.tr._n_flat
+        ops.axpby(0.0, self.flat[:n], 1.0 / (self.world * loss_scale), self.flat[:n])
+        for k in G:  # the dict the caller sees: views of the reduced buffer
+            off = self.tr._offsets[k]
+            G[k] = self.flat[off: off + G[k].numel()].view(G[k].shape)
+
+    def reduce_tail(self):
+        w = self._all_reduce(self.flat[self.tr._n_flat:])
+        if w is not None:
+            w.wait()

@@ -389,3 +389,33 @@ def test_training_step_with_dropout_directional_derivative_and_determinism():
     fd = (vals[0] - vals[1]) / (2 * eps)
     print(f"\n[dropout step] |grad| {norm:.5f}  finite difference {fd:.5f}  losses {vals}")
     assert abs(fd - norm) <= 0.01 * norm
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x2"])
+def test_overlapped_reducer_covers_every_gradient_once(precision):
+    """The overlapped all-reduce (launched per bucket while the backward runs) with a stand-in collective that doubles its
+    slice in place -- two identical ranks summed -- must leave, after the 1 / world scaling, exactly the gradients of the plain
+    path, every element reduced once, buckets launched from the last layer backwards with the head last."""
+    from didi_amd.trainer import _OverlappedReducer
+
+    t, meta, w, tr, ctx, tgt = _trainer("train_tiny_plain", precision)
+    kw = dict(draws=noise_list(t, int(meta["n_noise"])), t=t["t"])
+    plain = tr.flatten_gradients(tr.forward_backward(ctx, tgt, **kw)["grads"])[: tr._n_flat]
+    calls = []
+
+    def fake(slice_):
+        calls.append((slice_.data_ptr(), slice_.numel()))
+        slice_.mul_(2.0)
+        return None
+
+    sink = _OverlappedReducer(tr, 2, all_reduce=fake)
+    out = tr.forward_backward(ctx, tgt, grad_sink=sink, **kw)
+    assert torch.equal(sink.flat[: tr._n_flat], plain)
+    base = sink.flat.data_ptr()
+    spans = sorted(((p_ - base) // 4, (p_ - base) // 4 + n) for p_, n in calls)
+    assert spans[0][0] == 0 and spans[-1][1] == tr._n_flat and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    starts = [(p_ - base) // 4 for p_, _ in calls]
+    assert starts[:-1] == sorted(starts[:-1], reverse=True) and starts[-1] == 0  # last layers first, the head at the end
+    for k, g_ in out["grads"].items():  # the caller's dict now views the reduced buffer
+        off = tr._offsets[k]
+        assert g_.data_ptr() == base + 4 * off and tuple(g_.shape) == tuple(tr.params[k].shape)

@@ -48,3 +48,26 @@ def test_lambdas_drive_lambdalr_like_the_reference():
         sched.step()
     want = [lr_linear(k, o["lr"], o["min_lr"], o["warmup_steps"], o["decay_range"]) for k in range(8)]
     assert seen == pytest.approx(want) and seen[0] == 1e-4 and seen[-1] == 0.0 and math.isclose(seen[4], 0.5e-4)
+
+
+def test_layer_buckets_tile_the_flat_buffer():
+    """Bucket plan of the overlapped gradient reduction: launched from the last layer backwards, two layers per bucket, the head
+    (everything before layer 0) last; together they cover [0, n_flat) exactly once."""
+    from didi_amd.trainer import layer_buckets
+
+    for L, per in ((12, 2), (5, 2), (1, 2), (7, 3), (2, 1)):
+        head = 1000
+        width = 7_087_872
+        ranges = [(head + i * width, head + (i + 1) * width) for i in range(L)]
+        buckets, h = layer_buckets(ranges, head + L * width, per)
+        assert h == (0, head)
+        assert [b[0] for b in buckets] == sorted((b[0] for b in buckets), reverse=True)  # launch order follows the backward
+        covered = sorted([(b[1], b[2]) for b in buckets] + [h])
+        assert covered[0][0] == 0 and covered[-1][1] == head + L * width
+        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+        assert all((b[2] - b[1]) // width <= per for b in buckets)
+        # a bucket is launched when its FIRST (lowest) layer is done: by then the layers above it in the bucket are done too
+        for first, start, end in buckets:
+            assert start == ranges[first][0]
+    with pytest.raises(AssertionError):
+        layer_buckets([(0, 10), (12, 20)], 20)

@@ -133,14 +133,15 @@ extern "C" int didi_layernorm(const float* x, const float* gamma, const float* b
     DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
     const int f16 = plane_format == DIDI_FMT_FP16;
     DIDI_CHECK_ARG(!(y_lo && !y_hi));
-    if (H % 4 != 0 || H > 2048) return DIDI_ERR_UNSUPPORTED;
+    if (H % 4 != 0 || H > 4096) return DIDI_ERR_UNSUPPORTED;  // 4096: the widest context encoder the reference names (T5 v1.1 xxl)
     if (M == 0) return DIDI_OK;
     const int grid = cdiv(M, 4);
     hipStream_t st = as_stream(stream);
     if (H <= 256) layernorm_kernel<1><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32, f16);
     else if (H <= 768) layernorm_kernel<3><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32, f16);
     else if (H <= 1280) layernorm_kernel<5><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32, f16);
-    else layernorm_kernel<8><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32, f16);
+    else if (H <= 2048) layernorm_kernel<8><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32, f16);
+    else layernorm_kernel<16><<<grid, 256, 0, st>>>(x, gamma, beta, eps, M, H, y_hi, y_lo, y_f32, f16);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }
@@ -190,14 +191,15 @@ extern "C" int didi_rmsnorm(const float* x, const float* gamma, float eps, int M
     DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
     const int f16 = plane_format == DIDI_FMT_FP16;
     DIDI_CHECK_ARG(!(y_lo && !y_hi));
-    if (H % 4 != 0 || H > 2048) return DIDI_ERR_UNSUPPORTED;
+    if (H % 4 != 0 || H > 4096) return DIDI_ERR_UNSUPPORTED;
     if (M == 0) return DIDI_OK;
     const int grid = cdiv(M, 4);
     hipStream_t st = as_stream(stream);
     if (H <= 256) rmsnorm_kernel<1><<<grid, 256, 0, st>>>(x, gamma, eps, M, H, y_hi, y_lo, y_f32, f16);
     else if (H <= 768) rmsnorm_kernel<3><<<grid, 256, 0, st>>>(x, gamma, eps, M, H, y_hi, y_lo, y_f32, f16);
     else if (H <= 1280) rmsnorm_kernel<5><<<grid, 256, 0, st>>>(x, gamma, eps, M, H, y_hi, y_lo, y_f32, f16);
-    else rmsnorm_kernel<8><<<grid, 256, 0, st>>>(x, gamma, eps, M, H, y_hi, y_lo, y_f32, f16);
+    else if (H <= 2048) rmsnorm_kernel<8><<<grid, 256, 0, st>>>(x, gamma, eps, M, H, y_hi, y_lo, y_f32, f16);
+    else rmsnorm_kernel<16><<<grid, 256, 0, st>>>(x, gamma, eps, M, H, y_hi, y_lo, y_f32, f16);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

@@ -577,34 +577,35 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
         __syncthreads();
     }
     if constexpr (!BWD) {
-        // ---- O = dropout(P) V: rows ty + 16 i, columns 4 tx .. 4 tx + 3
-        for (int r0 = 0; r0 < Sq; r0 += 64) {
-            const int no = min(tx * 4, D - 4);
-            float acc[4][4] = {};
-            int ra[4];
+        // ---- O = dropout(P) V: rows ty + 16 i, columns n0 + 4 tx .. + 3 (n0 walks blocks of 64 columns: head dims up to 128)
+        for (int r0 = 0; r0 < Sq; r0 += 64)
+            for (int n0 = 0; n0 < D; n0 += 64) {
+                const int no = min(n0 + tx * 4, D - 4);
+                float acc[4][4] = {};
+                int ra[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = min(r0 + ty + 16 * i, Sq - 1) * LP;
-            for (int kk = 0; kk < Sk4; kk += 4) {
-                float4 a[4];
+                for (int i = 0; i < 4; ++i) ra[i] = min(r0 + ty + 16 * i, Sq - 1) * LP;
+                for (int kk = 0; kk < Sk4; kk += 4) {
+                    float4 a[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a[i] = ld4(P + ra[i] + kk);
-                    a[i].x = fmaxf(a[i].x, 0.f); a[i].y = fmaxf(a[i].y, 0.f); a[i].z = fmaxf(a[i].z, 0.f); a[i].w = fmaxf(a[i].w, 0.f);
+                    for (int i = 0; i < 4; ++i) {
+                        a[i] = ld4(P + ra[i] + kk);
+                        a[i].x = fmaxf(a[i].x, 0.f); a[i].y = fmaxf(a[i].y, 0.f); a[i].z = fmaxf(a[i].z, 0.f); a[i].w = fmaxf(a[i].w, 0.f);
+                    }
+                    const float4 b0 = ld4(v + min(kk, Sk - 1) * LD + no), b1 = ld4(v + min(kk + 1, Sk - 1) * LD + no),
+                                 b2 = ld4(v + min(kk + 2, Sk - 1) * LD + no), b3 = ld4(v + min(kk + 3, Sk - 1) * LD + no);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { fma4(acc[i], a[i].x, b0); fma4(acc[i], a[i].y, b1); fma4(acc[i], a[i].z, b2); fma4(acc[i], a[i].w, b3); }
                 }
-                const float4 b0 = ld4(v + min(kk, Sk - 1) * LD + no), b1 = ld4(v + min(kk + 1, Sk - 1) * LD + no),
-                             b2 = ld4(v + min(kk + 2, Sk - 1) * LD + no), b3 = ld4(v + min(kk + 3, Sk - 1) * LD + no);
+                if (no == n0 + tx * 4)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { fma4(acc[i], a[i].x, b0); fma4(acc[i], a[i].y, b1); fma4(acc[i], a[i].z, b2); fma4(acc[i], a[i].w, b3); }
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = r0 + ty + 16 * i;
+                        if (r < Sq)
+                            *reinterpret_cast<float4*>(p.O + ((size_t)b * Sq + r) * p.ldo + h * D + no) =
+                                make_float4(acc[i][0] * inv_keep, acc[i][1] * inv_keep, acc[i][2] * inv_keep, acc[i][3] * inv_keep);
+                    }
             }
-            if (no == tx * 4)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = r0 + ty + 16 * i;
-                    if (r < Sq)
-                        *reinterpret_cast<float4*>(p.O + ((size_t)b * Sq + r) * p.ldo + h * D + no) =
-                            make_float4(acc[i][0] * inv_keep, acc[i][1] * inv_keep, acc[i][2] * inv_keep, acc[i][3] * inv_keep);
-                }
-        }
         return;
     } else {
         // ---- dV = dropout(P)^T dO
@@ -707,7 +708,9 @@ static int attention_train_launch(const didi_attn_train_args* a, bool bwd, void*
     DIDI_CHECK_ARG(a->drop_p >= 0.f && a->drop_p < 1.f);
     if (bwd) DIDI_CHECK_ARG(a->dO && a->dQ && a->dK && a->dV);
     else DIDI_CHECK_ARG(a->O);
-    if (a->Sq > 96 || a->Sk > 96 || a->D > 64 || a->D % 4 != 0) return DIDI_ERR_UNSUPPORTED;
+    // the forward takes head dims up to 128 (context encoders with 80- or 128-wide heads: Blenderbot-3B, T5-3B) as long as one
+    // head's operands fit the LDS (checked below); the backward's dQ / dV stages are written for D <= 64
+    if (a->Sq > 96 || a->Sk > 96 || a->D > (bwd ? 64 : 128) || a->D % 4 != 0) return DIDI_ERR_UNSUPPORTED;
     if (a->causal && a->Sq != a->Sk) return DIDI_ERR_BAD_ARG;
     // 16-byte loads and stores of head slices: leading dimensions in multiples of 4 floats, bases 16-byte aligned
     const int hd = a->heads * a->D;

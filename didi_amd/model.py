@@ -273,8 +273,13 @@ class DiDiSampler:
         E, A = cfg.enc_dim, cfg.enc_heads
         mask32 = attention_mask.to(torch.int32).contiguous()
 
-        def attn(qkv_hi, qkv_lo):
+        wide_heads = E // A > 64 or (E // A) % 8 != 0  # e.g. Blenderbot-3B's 80-wide heads (configs/train.yaml:3)
+
+        def attn(qkv_hi, qkv_lo, qkv_f32=None):
             v = lambda t, i: None if t is None else t.view(B, Cn, 3 * E)[:, :, i * E:(i + 1) * E]  # noqa: E731
+            if wide_heads:  # past the MFMA attention kernel's head dim: the fp32 LDS kernel of the training forward (cold path)
+                o = ops.attention_train(v(qkv_f32, 0), v(qkv_f32, 1), v(qkv_f32, 2), A, causal=False, key_mask=mask32)
+                return ops.split(o.view(B * Cn, E))
             q, k, vv = ((v(qkv_hi, i), v(qkv_lo, i)) for i in range(3))
             o_hi, o_lo = ops.attention(q, k, vv, A, causal=False, key_mask=mask32, precision=P)
             return o_hi.view(B * Cn, E), o_lo.view(B * Cn, E)
@@ -284,8 +289,8 @@ class DiDiSampler:
             h = ops.embed_gather(input_ids, e["tok"], scale, e["pos"]).view(B * Cn, E)
             for ly in e["layers"]:
                 y_hi, y_lo, _ = ops.layernorm(h, *ly["ln1"], cfg.enc_ln_eps)
-                qkv_hi, qkv_lo, _ = ly["qkv"](y_hi, y_lo, P)
-                a_hi, a_lo = attn(qkv_hi, qkv_lo)
+                qkv_hi, qkv_lo, qkv32 = ly["qkv"](y_hi, y_lo, P, out_f32=wide_heads)
+                a_hi, a_lo = attn(qkv_hi, qkv_lo, qkv32)
                 _, _, h = ly["out"](a_hi, a_lo, P, residual=h, out_f32=True, out_planes=False)
                 y_hi, y_lo, _ = ops.layernorm(h, *ly["ln2"], cfg.enc_ln_eps)
                 f_hi, f_lo, _ = ly["fc1"](y_hi, y_lo, P, act="gelu")
@@ -324,8 +329,8 @@ class DiDiSampler:
                               tok_type0=e["tok0"], ln_gamma=e["eln"][0], ln_beta=e["eln"][1], ln_eps=1e-12, h_hi=h_hi, h_lo=h_lo)
             ctx = None
             for ly in e["layers"]:
-                qkv_hi, qkv_lo, _ = ly["qkv"](h_hi, h_lo, P)
-                a_hi, a_lo = attn(qkv_hi, qkv_lo)
+                qkv_hi, qkv_lo, qkv32 = ly["qkv"](h_hi, h_lo, P, out_f32=wide_heads)
+                a_hi, a_lo = attn(qkv_hi, qkv_lo, qkv32)
                 _, _, t = ly["out"](a_hi, a_lo, P, residual_planes=(h_hi, h_lo), out_f32=True, out_planes=False)
                 h_hi, h_lo, _ = ops.layernorm(t, *ly["ln1"], 1e-12)
                 f_hi, f_lo, _ = ly["fc1"](h_hi, h_lo, P, act="gelu")

@@ -523,8 +523,9 @@ int didi_attention_backward(const float* Q, const float* K, const float* V, cons
                             float* dV, void* stream);
 /* Attention of the TRAINING step in fp32 (forward and backward share one mask definition for attention-probability dropout,
  * HF:models/bert/modeling_bert.py:129): O = dropout(softmax(Q K^T scale + masks)) V and its backward.  Operands fp32, addressed
- * as didi_attention addresses its planes ([B*S, ld] row-major, head h at columns h*D..); Sq, Sk <= 96, D <= 64, D % 4 == 0,
- * leading dimensions % 4 == 0, bases 16-byte aligned.  Dropout: element (b, h, i, j) is dropped iff word (j & 3) of
+ * as didi_attention addresses its planes ([B*S, ld] row-major, head h at columns h*D..); Sq, Sk <= 96, D % 4 == 0, D <= 64
+ * (the forward alone: D <= 128 while one head's Q, K, V and scores fit the 160 KiB of LDS -- the context encoders with 80- or
+ * 128-wide heads run their attention through it), leading dimensions % 4 == 0, bases 16-byte aligned.  Dropout: element (b, h, i, j) is dropped iff word (j & 3) of
  * Philox4x32-10(counter = offset + (((b heads + h) Sq + i) Sk4 + j) / 4, key = seed) < drop_p 2^32 (Sk4 = Sk rounded up to 4);
  * the backward must be given the forward's (drop_p, seed, offset).  The sampler never runs these. */
 typedef struct didi_attn_train_args {

@@ -225,6 +225,22 @@ def t5_cases():
         save_case(name, spec, run, logits, draws, calls, ctx.detach(), ids, mask, weights=state_dict_of(m))
 
 
+TINY_BB_D80 = dict(vocab=600, enc_kind="blenderbot", enc_dim=160, enc_layers=2, enc_heads=2, enc_ffn=320,
+                   dec_dim=128, dec_layers=2, dec_heads=4, dec_ffn=512, T=10, schedule="sqrt")
+
+
+def wide_head_cases():
+    """(W) A Blenderbot context encoder with 80-wide attention heads, the head dim of facebook/blenderbot-3B (d_model 2560 / 32
+    heads), which configs/train.yaml:3 lists as a base model: past the MFMA attention kernel's head dim of 64."""
+    name, spec, seed = "tiny_bbd80_ddpm_f2", TINY_BB_D80, 15
+    m = build_model(spec, seed=seed)
+    ids, mask = make_inputs(3, 20, spec["vocab"], seed=seed + 20)
+    run = dict(mode="ddpm", step_freq=2, max_len=12, noise_seed=200 + seed)
+    logits, draws, calls = run_case(m, ids, mask, run["mode"], run["step_freq"], run["max_len"], run["noise_seed"])
+    ctx = m(encoder_input_ids=ids, encoder_attention_mask=mask, decoder_inputs_embeds=calls[0], time_ids=torch.ones(3, 1, dtype=torch.long))[1]
+    save_case(name, spec, run, logits, draws, calls, ctx.detach(), ids, mask, weights=state_dict_of(m))
+
+
 def ref_training_step(model, ctx, tgt, anchor_loss, noise_factor, tap):
     """DiDi.training_step (src/diffusion/model.py:200-243) around the HF modules, line for line, with the reference's own
     ``get_x0`` / ``get_diffusion_variables`` / ``scale_input`` imported from /root/reference (they import only torch).
@@ -331,6 +347,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "t5":  # add the T5 cases without regenerating the others
         t5_cases()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":  # add the wide-head encoder case without regenerating the others
+        wide_head_cases()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "train":  # add the training-step cases without regenerating the others
         training_cases()

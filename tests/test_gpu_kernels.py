@@ -588,3 +588,38 @@ def test_attention_fp16x3_three_products(ops):
     assert o_lo is not None and rel_l2(ops.join(o_hi, o_lo), want) <= 2e-5
     o1, _ = ops.attention(qp, kp, vp, heads, causal=False, key_mask=mask.cuda(), precision="fp16")
     assert rel_l2(o1.float(), want) > rel_l2(ops.join(o_hi, o_lo), want)
+
+
+@pytest.mark.parametrize("H", [2560, 4096, 2052])
+def test_layernorm_and_rmsnorm_wide_rows(H):
+    """Context encoders wider than 2048 (Blenderbot-3B 2560, T5 v1.1 xxl 4096)."""
+    from didi_amd import ops
+
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(37, H, generator=g) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(H, generator=g), 0.1 * torch.randn(H, generator=g)
+    hi, lo, y = ops.layernorm(x.cuda(), gamma.cuda(), beta.cuda(), 1e-5, f32=True)
+    want = torch.nn.functional.layer_norm(x.double(), (H,), gamma.double(), beta.double(), 1e-5)
+    assert rel_l2(y, want) <= 1e-6 and rel_l2(ops.join(hi, lo), want) <= 2e-5
+    hi, lo, y = ops.rmsnorm(x.cuda(), gamma.cuda(), 1e-6, f32=True)
+    want = x.double() * torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-6) * gamma.double()
+    assert rel_l2(y, want) <= 1e-6 and rel_l2(ops.join(hi, lo), want) <= 2e-5
+
+
+@pytest.mark.parametrize("B,heads,Sq,Sk,D", [(2, 2, 20, 20, 80), (2, 4, 64, 64, 128), (1, 3, 96, 96, 80), (2, 2, 33, 47, 96)])
+def test_attention_train_forward_wide_heads(B, heads, Sq, Sk, D):
+    """Head dims past 64 (the fp32 attention the wide-head context encoders run through), with a key padding mask."""
+    import math
+
+    from didi_amd import ops
+
+    g = torch.Generator().manual_seed(D + Sq)
+    H = heads * D
+    q, k, v = (torch.randn(B, s_, H, generator=g) for s_ in (Sq, Sk, Sk))
+    mask = torch.ones(B, Sk, dtype=torch.int32)
+    mask[0, Sk - 5:] = 0
+    sh = lambda t, S: t.double().view(B, S, heads, D).transpose(1, 2)  # noqa: E731
+    s = sh(q, Sq) @ sh(k, Sk).transpose(-1, -2) / math.sqrt(D) + (1.0 - mask[:, None, None, :].double()) * torch.finfo(torch.float32).min
+    want = (torch.softmax(s, -1) @ sh(v, Sk)).transpose(1, 2).reshape(B, Sq, H)
+    got = ops.attention_train(q.cuda(), k.cuda(), v.cuda(), heads, key_mask=mask.cuda())
+    assert rel_l2(got, want) <= 2e-6

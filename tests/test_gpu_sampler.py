@@ -42,14 +42,14 @@ def _model(weights, cfg, precision):
 TINY_CASES = ["tiny_ddpm_f1", "tiny_ddpm_f3_len8", "tiny_euler_f2", "tiny_euler_churn_f4"]
 
 
-@pytest.mark.parametrize("name", TINY_CASES + ["tiny_bertenc_ddpm_f2", "tiny_t5enc_ddpm_f2", "tiny_t5gated_euler_f3"])
+@pytest.mark.parametrize("name", TINY_CASES + ["tiny_bertenc_ddpm_f2", "tiny_t5enc_ddpm_f2", "tiny_t5gated_euler_f3", "tiny_bbd80_ddpm_f2"])
 @pytest.mark.parametrize("precision", ["bf16x3", "fp16x2", "fp16", "bf16"])
 def test_golden_cases(name, precision):
     from didi_amd.sampling import sample
 
     t, meta = load_case(name)
     spec, run = meta["spec"], meta["run"]
-    w = weights_of(t) if name.startswith(("tiny_bertenc", "tiny_t5")) else weights_of(load_case("tiny_weights")[0])
+    w = weights_of(t) if name.startswith(("tiny_bertenc", "tiny_t5", "tiny_bbd80")) else weights_of(load_case("tiny_weights")[0])
     model = _model(w, spec_to_config(spec), precision)
     noise = torch.stack(noise_list(t, int(meta["n_noise"])))
     ctx = _ctx(t["in.input_ids"], t["in.attention_mask"])

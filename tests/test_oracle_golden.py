@@ -68,6 +68,19 @@ def test_bert_encoder_case():
     assert torch.equal(logits.argmax(-1), t["out.ids"])
 
 
+def test_wide_head_blenderbot_encoder_case():
+    """A Blenderbot context encoder with 80-wide heads (facebook/blenderbot-3B's head dim; configs/train.yaml:3): fixture from
+    HF's BlenderbotEncoder under the reference sampler (oracle/make_golden.py wide)."""
+    t, meta, model, trace, logits = _run_case("tiny_bbd80_ddpm_f2")
+    assert meta["spec"]["enc_dim"] // meta["spec"]["enc_heads"] == 80 and model.has_adapter
+    ctx = model.encode_context(t["in.input_ids"], t["in.attention_mask"])
+    assert rel_l2(ctx, t["out.context"]) <= 1e-5
+    for i, x in enumerate(trace):
+        assert rel_l2(x, t[f"xt.{i}"]) <= 1e-5
+    assert rel_l2(logits, t["out.logits"]) <= 1e-5
+    assert torch.equal(logits.argmax(-1), t["out.ids"])
+
+
 @pytest.mark.parametrize("name,adapter", [("tiny_t5enc_ddpm_f2", True), ("tiny_t5gated_euler_f3", False)])
 def test_t5_encoder_cases(name, adapter):
     """T5EncoderModel contexts (model.py:39-42), ReLU and gated-GELU FFN, 40-token contexts (log-spaced position buckets):

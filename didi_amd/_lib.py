@@ -72,7 +72,7 @@ class AttnTrainArgs(C.Structure):
         ("B", C.c_int), ("heads", C.c_int), ("Sq", C.c_int), ("Sk", C.c_int), ("D", C.c_int),
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int), ("causal", C.c_int),
         ("scale", C.c_float), ("drop_p", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64),
-        ("O", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p),
+        ("O", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p), ("pos_bias", C.c_void_p),
     ]
 
 

@@ -536,6 +536,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
                 const int r = r0 + ty + 16 * i, c = tx + 16 * j;
                 if (r < Sq && c < Sk) {
                     float sc = acc[i][j] * scale;
+                    if (p.pos_bias) sc += p.pos_bias[((size_t)h * Sq + r) * Sk + c];  // T5's relative position bias
                     if ((p.key_mask && p.key_mask[(size_t)b * Sk + c] == 0) || (p.causal && c > r)) sc = fminf(sc + NEG, NEG);
                     P[r * LP + c] = sc;
                 }
@@ -706,7 +707,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
 static int attention_train_launch(const didi_attn_train_args* a, bool bwd, void* stream) {
     DIDI_CHECK_ARG(a && a->Q && a->K && a->V && a->B >= 0 && a->heads > 0 && a->Sq > 0 && a->Sk > 0 && a->D > 0);
     DIDI_CHECK_ARG(a->drop_p >= 0.f && a->drop_p < 1.f);
-    if (bwd) DIDI_CHECK_ARG(a->dO && a->dQ && a->dK && a->dV);
+    if (bwd) DIDI_CHECK_ARG(a->dO && a->dQ && a->dK && a->dV && !a->pos_bias);  // the bias is a forward-only feature (frozen T5 encoders)
     else DIDI_CHECK_ARG(a->O);
     // the forward takes head dims up to 128 (context encoders with 80- or 128-wide heads: Blenderbot-3B, T5-3B) as long as one
     // head's operands fit the LDS (checked below); the backward's dQ / dV stages are written for D <= 64

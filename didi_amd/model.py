@@ -300,8 +300,14 @@ class DiDiSampler:
             inner = A * cfg.enc_dkv
             bias = self._t5_position_bias(Cn)
 
-            def attn_t5(qkv_hi, qkv_lo):
+            wide_t5 = cfg.enc_dkv > 64 or cfg.enc_dkv % 8 != 0  # t5-3b / t5-11b: d_kv = 128
+
+            def attn_t5(qkv_hi, qkv_lo, qkv_f32=None):
                 v = lambda t, i: t.view(B, Cn, 3 * inner)[:, :, i * inner:(i + 1) * inner]  # noqa: E731
+                if wide_t5:
+                    o = ops.attention_train(v(qkv_f32, 0), v(qkv_f32, 1), v(qkv_f32, 2), A, causal=False, key_mask=mask32, scale=1.0,
+                                            pos_bias=bias)
+                    return ops.split(o.view(B * Cn, inner))
                 q, k, vv = ((v(qkv_hi, i), v(qkv_lo, i)) for i in range(3))
                 o_hi, o_lo = ops.attention(q, k, vv, A, causal=False, key_mask=mask32, precision=P, scale=1.0, pos_bias=bias)
                 return o_hi.view(B * Cn, inner), o_lo.view(B * Cn, inner)
@@ -309,8 +315,8 @@ class DiDiSampler:
             h = ops.embed_gather(input_ids, e["tok"]).view(B * Cn, E)
             for ly in e["layers"]:
                 y_hi, y_lo, _ = ops.rmsnorm(h, ly["ln1"], cfg.enc_ln_eps)
-                qkv_hi, qkv_lo, _ = ly["qkv"](y_hi, y_lo, P)
-                a_hi, a_lo = attn_t5(qkv_hi, qkv_lo)
+                qkv_hi, qkv_lo, qkv32 = ly["qkv"](y_hi, y_lo, P, out_f32=wide_t5)
+                a_hi, a_lo = attn_t5(qkv_hi, qkv_lo, qkv32)
                 _, _, h = ly["out"](a_hi, a_lo, P, residual=h, out_f32=True, out_planes=False)
                 y_hi, y_lo, _ = ops.rmsnorm(h, ly["ln2"], cfg.enc_ln_eps)
                 if cfg.enc_gated_ffn:

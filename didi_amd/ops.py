@@ -416,10 +416,13 @@ def _attn_train_args(q, k, v, heads, causal, key_mask, scale, drop_p, seed, offs
     return a
 
 
-def attention_train(q, k, v, heads, causal=False, key_mask=None, scale=None, drop_p=0.0, seed=0, offset=0):
-    """Training-step attention in fp32: O = dropout(softmax(q k^T scale + masks)) v -> fp32 [B, Sq, heads*D] contiguous.
-    q/k/v fp32 [B, S, heads*D] (row-strided views of a fused projection are fine)."""
+def attention_train(q, k, v, heads, causal=False, key_mask=None, scale=None, drop_p=0.0, seed=0, offset=0, pos_bias=None):
+    """Training-step attention in fp32: O = dropout(softmax(q k^T scale + pos_bias + masks)) v -> fp32 [B, Sq, heads*D] contiguous.
+    q/k/v fp32 [B, S, heads*D] (row-strided views of a fused projection are fine); ``pos_bias`` fp32 [heads, Sq, Sk] (T5)."""
     a = _attn_train_args(q, k, v, heads, causal, key_mask, scale, drop_p, seed, offset)
+    if pos_bias is not None:
+        assert pos_bias.dtype == torch.float32 and pos_bias.is_contiguous() and tuple(pos_bias.shape) == (heads, a.Sq, a.Sk)
+        a.pos_bias = pos_bias.data_ptr()
     out = torch.empty((a.B, a.Sq, a.heads * a.D), dtype=torch.float32, device=q.device)
     a.O = out.data_ptr()
     _lib.check(lib.didi_attention_train_forward(C.byref(a), _lib.current_stream()), "attention_train_forward")

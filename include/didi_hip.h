@@ -540,6 +540,7 @@ typedef struct didi_attn_train_args {
     uint64_t seed, offset;
     float* O;                 /* forward output [B*Sq, ldo] */
     float *dQ, *dK, *dV;      /* backward outputs, laid out like Q, K, V */
+    const float* pos_bias;    /* forward only: fp32 [heads, Sq, Sk] added to the scaled scores (T5), or NULL */
 } didi_attn_train_args;
 int didi_attention_train_forward(const didi_attn_train_args* a, void* stream);
 int didi_attention_train_backward(const didi_attn_train_args* a, void* stream);

@@ -229,6 +229,23 @@ TINY_BB_D80 = dict(vocab=600, enc_kind="blenderbot", enc_dim=160, enc_layers=2, 
                    dec_dim=128, dec_layers=2, dec_heads=4, dec_ffn=512, T=10, schedule="sqrt")
 
 
+TINY_T5_D128 = dict(vocab=600, enc_kind="t5", enc_dim=96, enc_dkv=128, enc_layers=2, enc_heads=2, enc_ffn=256, enc_ffn_act="relu",
+                    dec_dim=128, dec_layers=2, dec_heads=4, dec_ffn=512, T=10, schedule="sqrt")
+
+
+def wide_t5_case():
+    """(W2) A T5 context encoder with d_kv = 128 (t5-3b / t5-11b), 40-token contexts, position bias widened as in t5_cases."""
+    name, spec, seed = "tiny_t5d128_ddpm_f2", TINY_T5_D128, 16
+    m = build_model(spec, seed=seed)
+    with torch.no_grad():
+        m.encoder.encoder.block[0].layer[0].SelfAttention.relative_attention_bias.weight.mul_(4.0)
+    ids, mask = make_inputs(3, 40, spec["vocab"], seed=seed + 20)
+    run = dict(mode="ddpm", step_freq=2, max_len=16, noise_seed=200 + seed)
+    logits, draws, calls = run_case(m, ids, mask, run["mode"], run["step_freq"], run["max_len"], run["noise_seed"])
+    ctx = m(encoder_input_ids=ids, encoder_attention_mask=mask, decoder_inputs_embeds=calls[0], time_ids=torch.ones(3, 1, dtype=torch.long))[1]
+    save_case(name, spec, run, logits, draws, calls, ctx.detach(), ids, mask, weights=state_dict_of(m))
+
+
 def wide_head_cases():
     """(W) A Blenderbot context encoder with 80-wide attention heads, the head dim of facebook/blenderbot-3B (d_model 2560 / 32
     heads), which configs/train.yaml:3 lists as a base model: past the MFMA attention kernel's head dim of 64."""
@@ -350,6 +367,7 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "wide":  # add the wide-head encoder case without regenerating the others
         wide_head_cases()
+        wide_t5_case()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "train":  # add the training-step cases without regenerating the others
         training_cases()

@@ -42,7 +42,8 @@ def _model(weights, cfg, precision):
 TINY_CASES = ["tiny_ddpm_f1", "tiny_ddpm_f3_len8", "tiny_euler_f2", "tiny_euler_churn_f4"]
 
 
-@pytest.mark.parametrize("name", TINY_CASES + ["tiny_bertenc_ddpm_f2", "tiny_t5enc_ddpm_f2", "tiny_t5gated_euler_f3", "tiny_bbd80_ddpm_f2"])
+@pytest.mark.parametrize("name", TINY_CASES + ["tiny_bertenc_ddpm_f2", "tiny_t5enc_ddpm_f2", "tiny_t5gated_euler_f3", "tiny_bbd80_ddpm_f2",
+                                                "tiny_t5d128_ddpm_f2"])
 @pytest.mark.parametrize("precision", ["bf16x3", "fp16x2", "fp16", "bf16"])
 def test_golden_cases(name, precision):
     from didi_amd.sampling import sample

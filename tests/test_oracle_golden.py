@@ -81,7 +81,7 @@ def test_wide_head_blenderbot_encoder_case():
     assert torch.equal(logits.argmax(-1), t["out.ids"])
 
 
-@pytest.mark.parametrize("name,adapter", [("tiny_t5enc_ddpm_f2", True), ("tiny_t5gated_euler_f3", False)])
+@pytest.mark.parametrize("name,adapter", [("tiny_t5enc_ddpm_f2", True), ("tiny_t5gated_euler_f3", False), ("tiny_t5d128_ddpm_f2", True)])
 def test_t5_encoder_cases(name, adapter):
     """T5EncoderModel contexts (model.py:39-42), ReLU and gated-GELU FFN, 40-token contexts (log-spaced position buckets):
     the fixture comes from HF's T5EncoderModel under the reference sampler."""

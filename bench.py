@@ -441,15 +441,17 @@ def main():
             "weights": "random-init N(0,0.02), seed 1234", "noise": "in-kernel Philox",
             "precision": args.precision,
             "precision_schedule": ({"timestep_thresholds": [list(x) for x in (model.schedule_euler if args.mode == "euler" else model.schedule)],
-                                    "tail_calls": [list(x) for x in model.tail_calls], "calls": {r[0]: r[1] for r in regimes}}
+                                    "tail_calls": [list(x) for x in model.tail_calls], "calls": {r[0]: r[1] for r in regimes},
+                                    "weight_dither": model.weight_dither}
                                    if model.schedule else None),
             "precision_note": {
                 "fp16-sched": ("fp16 operand planes where BASELINE configs[1] says bf16: 16-bit MFMA operands with fp32 accumulation either way; the "
                                "parity bar (ids >= 99.9 %, every x_t <= 1e-3 against the fp32 reference) decides what is multiplied: one-product "
-                               "bf16 / fp16 miss it at this model size (weight rounding adds up coherently over the loop), so calls run one "
-                               "product while x_t is mostly fresh noise, add the weights' remainder plane below t = 0.35 T and multiply all three "
-                               "products for the last 0.064 T steps: 0 of 1024 ids differ, max x_t rel-L2 5.7e-4 over 2000 calls "
-                               "(profiles/r02_parity_f1_ddpm.log, tests/test_gpu_fullsize.py)"),
+                               "bf16 / fp16 miss it at this model size (weight rounding adds up coherently over the loop), so ddpm calls run one "
+                               "product, cycling through 4 differently rounded copies of the weights, while t > 0.15 T, add the weights' "
+                               "remainder plane below that and multiply all three products for the last 0.064 T steps: 0 of 1024 ids differ, "
+                               "max x_t rel-L2 6.3e-4 over 2000 calls on two seed sets (profiles/r02_dither_probe_ddpm_f1*.log, "
+                               "tests/test_gpu_fullsize.py); euler loops run two products, then three"),
                 "fp16x2": "fp16 planes, A_hi*(W_hi+W_lo) in every call: holds the bars over 201 calls (step_freq 10), misses them over 2000",
                 "fp16": "one-product fp16: misses the parity bars at this model size (tests/test_gpu_fullsize.py); not a valid headline mode",
                 "bf16": "one-product bf16: misses the parity bars (99.46 % ids on the config-1 model); not a valid headline mode",

@@ -120,7 +120,7 @@ class SampleArgs(C.Structure):
         ("ids64", C.c_void_p),
         ("prof_calls_host", C.POINTER(C.c_int)), ("n_prof_calls", C.c_int), ("prof_events_host", C.POINTER(C.c_void_p)), ("prof_capacity", C.c_int),
         ("prof_used_host", C.POINTER(C.c_int)), ("clamp_emb", C.c_void_p), ("fault", C.c_void_p),
-        ("precision_host", C.POINTER(C.c_int)),
+        ("precision_host", C.POINTER(C.c_int)), ("dec_variants_host", C.POINTER(C.c_void_p)), ("n_variants", C.c_int),
     ]
 
 

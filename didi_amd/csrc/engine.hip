@@ -300,6 +300,8 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
     auto draw = [&](int i) -> const float* { return s->noise ? s->noise + (size_t)i * MH : nullptr; };
     // precision schedule: one precision per denoiser call (all on the plane format of `precision`)
     auto prec_of = [&](int k) { return s->precision_host ? s->precision_host[k] : s->precision; };
+    // one-product calls cycle through differently rounded copies of the weights (didi_sample_args.dec_variants_host)
+    auto dec_of = [&](int k) { return s->dec_variants_host && s->n_variants > 0 && prec_of(k) == DIDI_PREC_FP16 ? s->dec_variants_host[k % s->n_variants] : dec; };
     // per-step clamp extension: x0 <- emb[argmax(classifier(x0))]; the forward leaves x0 planes for the rounding GEMM
     const bool clamp = s->clamp_emb != nullptr;
     auto clamp_x0 = [&]() -> int {
@@ -340,7 +342,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
             const bool last = k == s->n_calls - 1;
             f.x0_hi = last || clamp ? s->x0_hi : nullptr;
             f.x0_lo = last || clamp ? s->x0_lo : nullptr;
-            TRY(didi_decoder_forward(dec, &f, stream));
+            TRY(didi_decoder_forward(dec_of(k), &f, stream));
             if (clamp) {
                 TRY(clamp_x0());
                 if (last) TRY(split_x0());  // the final rounding reads the planes of the clamped x0
@@ -371,7 +373,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
             f.x0_lo = clamp ? s->x0_lo : nullptr;
             f.precision = prec_of(k);
             set_prof(k);
-            TRY(didi_decoder_forward(dec, &f, stream));
+            TRY(didi_decoder_forward(dec_of(k), &f, stream));
             if (clamp) TRY(clamp_x0());
         }
         // final Euler update lands on sigma = 0 (src/sampling.py:80): x0 <- x + (x - x0_hat) * ratio

@@ -24,9 +24,14 @@ from .schedule import configure_schedule
 
 
 # Default precision schedule of "fp16-sched", as fractions of the number of diffusion steps T (measured at
-# T = 2000, sqrt schedule: t > 700 / t > 128 / the rest): one product while the input is mostly fresh noise, the weights'
-# remainder once x_t starts to carry the previous estimate, all three products for the last steps.
-DEFAULT_SCHEDULE = ((0.35, "fp16"), (0.064, "fp16x2"), (0, "fp16x3"))
+# T = 2000, sqrt schedule: t > 300 / t > 128 / the rest): one product while the input is mostly fresh noise, the weights'
+# remainder once x_t starts to carry the previous estimate, all three products for the last steps.  The one-product regime
+# reaches down to 0.15 T because its calls cycle through DEFAULT_WEIGHT_DITHER differently rounded copies of the weights: plain
+# rounding is the SAME perturbation of the model at every call and its effect adds up coherently over the loop (T = 2000, f = 1,
+# fp16 above 0.15 T: max x_t 1.0e-3 with one rounding, 6.4e-4 with four; without the copies the threshold was 0.35 T:
+# profiles/r02_dither_probe_*.log).
+DEFAULT_SCHEDULE = ((0.15, "fp16"), (0.064, "fp16x2"), (0, "fp16x3"))
+DEFAULT_WEIGHT_DITHER = 4
 # The euler sampler integrates an ODE: an error made at a high timestep shifts the trajectory for good instead of being drowned
 # by the next step's fresh noise as in ddpm (T = 2000, f = 10, final x_t: 2.7e-4 with the ddpm schedule whatever the tail, 4.2e-5
 # without a one-product regime; ids 4 vs 1 of 2048 on held-out seeds: profiles/r02_sched_probe_f10_euler.log,
@@ -81,19 +86,23 @@ class _Classifier:
 
 
 class DiDiSampler:
-    def __init__(self, state_dict, cfg: DiDiConfig, device="cuda", precision="bf16x3", schedule=None, tail_calls=None):
+    def __init__(self, state_dict, cfg: DiDiConfig, device="cuda", precision="bf16x3", schedule=None, tail_calls=None, weight_dither=None):
         """``precision``: bf16 | fp16 (one MFMA product), fp16x2 (weights with their remainder), bf16x3 (fp32-class), or
         "fp16-sched": fp16 planes with the default precision schedule ``DEFAULT_SCHEDULE``.
         ``schedule``: precision schedule of ``sample`` over the TIMESTEP of each denoiser call, a tuple of (t_above, precision)
         pairs in decreasing t: a call whose time-embedding row is > t_above runs in that precision (fp16 | fp16x2 | fp16x3);
         the last pair must have t_above = 0.  Needs an fp16-plane ``precision``.
         ``tail_calls``: (calls_from_the_end, precision) floors on top of the schedule: the last n calls of a loop run at least
-        that precision ("fp16-sched" defaults to ``DEFAULT_TAIL_CALLS``; an explicit schedule to none)."""
+        that precision ("fp16-sched" defaults to ``DEFAULT_TAIL_CALLS``; an explicit schedule to none).
+        ``weight_dither``: P > 1 keeps P differently rounded fp16 copies of the per-call GEMM weights and cycles the one-product
+        calls of a loop through them (``_build_weight_variants``); fp16 planes only ("fp16-sched" defaults to
+        ``DEFAULT_WEIGHT_DITHER``, everything else to none)."""
         schedule_euler = None
         if precision == "fp16-sched":
             schedule_euler = None if schedule else DEFAULT_SCHEDULE_EULER  # an explicit schedule is used for both samplers
             precision, schedule = "fp16x2", (schedule or DEFAULT_SCHEDULE)
             tail_calls = DEFAULT_TAIL_CALLS if tail_calls is None else tail_calls
+            weight_dither = DEFAULT_WEIGHT_DITHER if weight_dither is None else weight_dither
         if precision not in ("bf16", "fp16", "fp16x2", "bf16x3"):
             raise ValueError("precision must be one of bf16, fp16, fp16x2, bf16x3, fp16-sched")
         def resolve(schedule):  # thresholds below 1 are fractions of T
@@ -117,6 +126,7 @@ class DiDiSampler:
         if schedule_euler is not None:
             schedule_euler = resolve(schedule_euler)
         self.cfg, self.device, self.precision = cfg, torch.device(device), precision
+        self.weight_dither = int(weight_dither or 0) if precision in ("fp16", "fp16x2") else 0
         self.schedule = schedule
         self.schedule_euler = schedule_euler if schedule_euler is not None else schedule  # "fp16-sched": DEFAULT_SCHEDULE_EULER
         self.tail_calls = tuple(tail_calls or ())  # an explicit schedule is taken as written unless floors are given too
@@ -189,6 +199,46 @@ class DiDiSampler:
         d.emb_ln_g, d.emb_ln_b = self._eln_g.data_ptr(), self._eln_b.data_ptr()
         d.layers_host = C.cast(layers, C.POINTER(_lib.DecoderLayer))
         self._layers, self._dec = layers, d
+        self._dec_variants = []
+        if self.weight_dither > 1:
+            self._build_weight_variants(sd)
+
+    def _build_weight_variants(self, sd):
+        """``weight_dither`` = P > 1: P copies of the per-call GEMM weights' hi planes, copy j rounding W + ((j + 1/2) / P - 1/2) ulp
+        to fp16 (ordered dither: the copies' mean is within ulp / 2P of W).  One-product (fp16) calls of a loop cycle through
+        them (didi_sample_args.dec_variants_host), so the weight-rounding error is not the same perturbation at every call."""
+        cfg, dev, P = self.cfg, self.device, self.weight_dither
+        names = ("qkv", "attn_out", "cq", "cross_out", "ffn_up", "ffn_down")
+        for j in range(P):
+            off = (j + 0.5) / P - 0.5
+            layers = (_lib.DecoderLayer * cfg.dec_layers)()
+            for i in range(cfg.dec_layers):
+                C.memmove(C.byref(layers[i]), C.byref(self._layers[i]), C.sizeof(_lib.DecoderLayer))
+                p = f"decoder.encoder.layer.{i}."
+                srcs = dict(
+                    qkv=torch.cat([sd[f"{p}attention.self.{n}.weight"] for n in ("query", "key", "value")], 0),
+                    attn_out=sd[p + "attention.output.dense.weight"], cq=sd[p + "crossattention.self.query.weight"],
+                    cross_out=sd[p + "crossattention.output.dense.weight"], ffn_up=sd[p + "intermediate.dense.weight"],
+                    ffn_down=sd[p + "output.dense.weight"])
+                for n in names:
+                    w = srcs[n].detach().to(device=dev, dtype=torch.float32)
+                    _, e = torch.frexp(w)
+                    ulp = torch.ldexp(torch.ones_like(w), (e - 11).clamp_min(-24))
+                    hi = torch.where(w == 0, w, w + off * ulp).to(torch.float16).contiguous()
+                    self._keep.append(hi)
+                    lin = getattr(layers[i], n)
+                    lin.w_hi = hi.data_ptr()
+            d = _lib.Decoder()
+            C.memmove(C.byref(d), C.byref(self._dec), C.sizeof(_lib.Decoder))
+            d.layers_host = C.cast(layers, C.POINTER(_lib.DecoderLayer))
+            self._dec_variants.append((d, layers))
+        self._dec_variant_ptrs = (C.c_void_p * P)(*[C.addressof(d) for d, _ in self._dec_variants])
+
+    def dec_for_call(self, k, prec):
+        """The decoder description call k of a loop runs with (Python-loop twin of the engine's choice)."""
+        if self._dec_variants and prec == _lib.PREC_FP16:
+            return self._dec_variants[k % len(self._dec_variants)][0]
+        return self._dec
 
     # ------------------------------------------------------------------ context encoder (cold path: once per batch)
     def _build_encoder(self, sd, f):

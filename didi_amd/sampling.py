@@ -137,6 +137,8 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
         precs = model.call_precisions(plan.time_row, mode)
         prec_arr = (C.c_int * n_calls)(*precs) if precs is not None else None  # kept alive until the call returns
         a.precision_host = prec_arr if prec_arr is not None else C.cast(None, C.POINTER(C.c_int))
+        if model._dec_variants:  # one-product calls cycle through differently rounded weight planes (DiDiSampler(weight_dither=P))
+            a.dec_variants_host, a.n_variants = model._dec_variant_ptrs, len(model._dec_variants)
         if _prof is not None:  # bench.py: HIP events around the GEMM launches of chosen denoiser calls
             a.prof_calls_host, a.n_prof_calls = _prof.calls, len(_prof.calls)
             a.prof_events_host, a.prof_capacity, a.prof_used_host = _prof.events, _prof.capacity, _prof.used
@@ -180,8 +182,8 @@ def _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp=False):
         fa = _lib.ForwardArgs()
         fa.B, fa.S, fa.C, fa.precision = B, S, Cn, (precs[k] if precs is not None else model.prec)
         st = fa.step
-        for k, v in step_kw.items():
-            setattr(st, k, v)
+        for key, v in step_kw.items():
+            setattr(st, key, v)
         st.t = t
         xin = None
         if trace is not None:
@@ -192,7 +194,7 @@ def _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp=False):
         fa.workspace, fa.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
         fa.x0_f32 = x0.data_ptr()
         fa.fault = b["fault"].data_ptr()
-        _lib.check(lib.didi_decoder_forward(C.byref(model._dec), C.byref(fa), _lib.current_stream()), "decoder_forward")
+        _lib.check(lib.didi_decoder_forward(C.byref(model.dec_for_call(k, fa.precision)), C.byref(fa), _lib.current_stream()), "decoder_forward")
         if clamp:
             clamp_x0()
         if trace is not None:

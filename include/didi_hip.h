@@ -466,6 +466,13 @@ typedef struct didi_sample_args {
      * they grow towards the end of the loop where x_t is mostly the previous estimate: the extra MFMA products are spent
      * where the bar needs them. */
     const int* precision_host;
+    /* weight variants for the ONE-PRODUCT (FP16) calls of the loop: NULL, or a HOST array of n_variants decoder descriptions that
+     * differ from `dec` only in the hi planes of the six per-call GEMM weights, each plane a different rounding of the same fp32
+     * weights (ordered dither: the variants' mean is 1 / n_variants of an fp16 ulp from the true weight).  Call k of precision
+     * FP16 runs variant k % n_variants, so the weight-rounding error is no longer the same perturbation at every call (which adds
+     * up coherently over the loop) but averages out over n_variants consecutive calls.  Calls of the other precisions use `dec`. */
+    const didi_decoder* const* dec_variants_host;
+    int n_variants;
 } didi_sample_args;
 int didi_sample(const didi_decoder* dec, const didi_sample_args* a, void* stream);
 

@@ -72,7 +72,7 @@ def main():
         ("bf16x3", dict(precision="bf16x3")),
         sched((0, "fp16x3")),
         ("fp16-sched (default) " + str(DEFAULT_SCHEDULE_EULER if mode == "euler" else DEFAULT_SCHEDULE), dict(precision="fp16-sched")),
-        sched((1000, "fp16"), (128, "fp16x2"), (0, "fp16x3")),
+        sched((700, "fp16"), (128, "fp16x2"), (0, "fp16x3")),
         sched((600, "fp16"), (0, "fp16x3")),
         ("fp16x2", dict(precision="fp16x2")),
     ]

@@ -352,7 +352,7 @@ def test_precision_schedule(name):
     sched = DiDiSampler(w, cfg, device="cuda", precision="fp16-sched")
     assert sched.tail_calls == DEFAULT_TAIL_CALLS and part.tail_calls == ()
     rows = list(range(2000, 1, -10)) + [1]
-    sched.schedule = ((700, "fp16"), (128, "fp16x2"), (0, "fp16x3"))  # the default's thresholds at T = 2000
+    sched.schedule = ((700, "fp16"), (128, "fp16x2"), (0, "fp16x3"))  # thresholds at 0.35 T / 0.064 T of T = 2000
     precs = sched.call_precisions(rows)
     assert precs.count(5) == 64 and all(p == 5 for p in precs[-64:]) and precs.count(2) == 130 and precs.count(4) == 7
     # euler integrates an ODE (errors persist): its default schedule has no one-product regime; an explicit schedule serves both
@@ -421,3 +421,61 @@ def test_full_size_decoder_properties():
     assert e_ctx <= 1e-4 and e_out <= 1e-4
     assert e_h <= 2e-3 and e_h40 <= 2e-3
     assert e_b <= 2e-2
+
+
+def test_weight_dither_variants_and_loops():
+    """``weight_dither`` = P: P fp16 roundings of every per-call GEMM weight whose MEAN is within ulp / 2P of the fp32 weight
+    (plain rounding: ulp / 2), each within one ulp of it; only one-product calls use them (an fp16x3-only loop is bit-identical
+    with and without), and the per-call Python loop picks the same variant per call as the native loop."""
+    from didi_amd import ops
+    from didi_amd.model import DiDiSampler
+    from didi_amd.sampling import sample
+
+    name = "tiny_ddpm_f1"
+    t, meta = load_case(name)
+    run = meta["run"]
+    w = weights_of(load_case("tiny_weights")[0])
+    cfg = spec_to_config(meta["spec"])
+    noise = torch.stack(noise_list(t, int(meta["n_noise"])))
+    ctx = _ctx(t["in.input_ids"], t["in.attention_mask"])
+    P = 4
+    m = DiDiSampler(w, cfg, device="cuda", precision="fp16", weight_dither=P)
+    assert len(m._dec_variants) == P
+    key = "decoder.encoder.layer.0.intermediate.dense.weight"
+    W = w[key].double()
+    planes = []
+    for d, layers in m._dec_variants:
+        n = W.numel()
+        buf = (torch.empty(0, dtype=torch.float16, device="cuda"))
+        # read the variant's ffn_up hi plane back through its raw pointer
+        ptr = layers[0].ffn_up.w_hi
+        hit = [x for x in m._keep if torch.is_tensor(x) and x.data_ptr() == ptr]
+        assert len(hit) == 1 and hit[0].dtype == torch.float16 and hit[0].numel() == n
+        planes.append(hit[0].double().cpu().view_as(W))
+    _, e = torch.frexp(W.float())
+    ulp = torch.ldexp(torch.ones_like(W.float()), (e - 11).clamp_min(-24)).double()
+    mean_err = (torch.stack(planes).mean(0) - W).abs() / ulp
+    rne_err = (W.half().double() - W).abs() / ulp
+    assert float(mean_err.max()) <= 0.5 / P + 0.26 and float(mean_err.mean()) < 0.5 * float(rne_err.mean())
+    assert all(float(((q - W).abs() / ulp).max()) <= 1.0 for q in planes)
+    assert len({q.numpy().tobytes() for q in planes}) == P
+    # native loop == Python loop, call by call, with variants in play
+    tr_a, tr_b = [], []
+    a, _ = sample(ctx, m, run["mode"], run["step_freq"], max_len=run["max_len"], noise=noise, return_ids=True, trace=tr_a)
+    worst = max(rel_l2(x, t[f"xt.{i}"]) for i, x in enumerate(tr_a))
+    assert worst <= 1e-3
+    torch.cuda.manual_seed(3)
+    shape = tuple(t["noise.0"].shape)
+    x_native = sample(ctx, m, run["mode"], run["step_freq"], max_len=run["max_len"], raw_output=True,
+                      noise=torch.stack([torch.randn(shape, device="cuda")] + [torch.empty(shape, device="cuda").normal_(0, 1) for _ in range(int(meta["n_noise"]) - 1)]))
+    torch.cuda.manual_seed(3)
+    x_python = sample(ctx, m, run["mode"], run["step_freq"], max_len=run["max_len"], raw_output=True, noise="torch")
+    assert torch.equal(x_native, x_python)
+    # variants are for one-product calls only
+    full = DiDiSampler(w, cfg, device="cuda", precision="fp16", schedule=((0, "fp16x3"),))
+    full_d = DiDiSampler(w, cfg, device="cuda", precision="fp16", schedule=((0, "fp16x3"),), weight_dither=P)
+    ia, _ = sample(ctx, full, run["mode"], run["step_freq"], max_len=run["max_len"], noise=noise, return_ids=True, trace=tr_b)
+    tr_c = []
+    ib, _ = sample(ctx, full_d, run["mode"], run["step_freq"], max_len=run["max_len"], noise=noise, return_ids=True, trace=tr_c)
+    assert torch.equal(ia, ib) and all(torch.equal(x, y) for x, y in zip(tr_b, tr_c))
+    assert DiDiSampler(w, cfg, device="cuda", precision="bf16x3", weight_dither=P)._dec_variants == []

@@ -94,7 +94,7 @@ def test_cfg2_size_loop_ids_and_xt_vs_oracle(mode, weights):
 
 
 def test_bench_shape_single_call_full_chip():
-    """B = 256, S = C = 64 (bench.py's shape): one denoiser call + rounding in fp16x2 (bench.py's default), fp16 and bf16x3.
+    """B = 256, S = C = 64 (bench.py's shape): one denoiser call + rounding in fp16x2, fp16 (the regimes of bench.py's default schedule, one by one) and bf16x3.
     Every output finite, no device fault, and the first 4 dialogs agree with the oracle."""
     from didi_amd import ops
     from didi_amd.config import DiDiConfig

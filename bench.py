@@ -7,7 +7,10 @@ lengths and (N > 1) the RCCL gather of token ids.  Default workload = BASELINE.j
 blenderbot-400M-distill-sized encoder + BertConfig-default decoder, T = 2000, step_freq = 1,
 batch 256 per GPU, context/target 64.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|bf16x3] [--mode ddpm|euler] [--freq F]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp16-sched|bf16x3|...] [--mode ddpm|euler] [--freq F]
+
+N > 1: either under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: RANK / WORLD_SIZE come
+from the environment) or bare (`python bench.py --gpus N`: this process spawns the N ranks itself, see spawn_ranks).
 
 Prints ONE JSON line on rank 0: metric/value (sampled dialogs/s, whole job), plus
   roofline     : the dominant kernel (MFMA GEMM), algorithmic FLOPs / launch duration measured with
@@ -270,14 +273,115 @@ def cpu_baseline_training(cfg, sd, batch, tr, slice_dialogs=64, passes=3):
                        f"batch, {threads} threads on '{cpu_model}': warm-up {times[0]:.2f}s, timed passes {', '.join(f'{x:.2f}s' for x in times[1:])} (fastest kept)")}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): this process becomes the launcher.
+    It has not touched the GPU (torch is imported, no device call is made, didi_amd._lib is not loaded) and never will: it starts
+    N fresh children of this same command line, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would, lets rank 0's single JSON line through on stdout, and exits non-zero if any rank fails (the
+    survivors are stopped: their collectives would wait for ever).  What Lightning does for the reference's training
+    (`Trainer(devices=8, strategy=DDPStrategy)`, src/training.py:37-47)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, text=True,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+
+    def relay():  # stdout carries the JSON line and nothing else: library chatter on rank 0's stdout (gloo prints there) goes to stderr
+        for line in procs[0].stdout:
+            print(line, end="", file=sys.stdout if line.lstrip().startswith("{") else sys.stderr, flush=True)
+
+    import threading
+
+    pump = threading.Thread(target=relay, daemon=True)
+    pump.start()
+    rc, left = 0, set(range(n))
+    while left:
+        for r in sorted(left):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            left.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in left:
+                    procs[q].terminate()
+        time.sleep(0.2)
+    pump.join(timeout=30)
+    return rc
+
+
+def main_rehearsal(args):
+    """`--device cpu`: the launch path of a multi-rank run (rank spawn, rendezvous, shard bounds, per-rank Philox ranges, the id
+    gather, barrier + max-over-ranks timing, one JSON line from rank 0) over gloo with a STUB in place of the sampler -- no kernel
+    runs and the line says so ("valid": false).  tests/test_dist_cpu.py runs it with --gpus 2; it exists so that the N > 1 command
+    the driver will use is exercised where there is one GPU or none."""
+    from didi_amd import dist as ddist
+    from didi_amd.synthetic import RawContext, synthetic_batch
+
+    rank, world, _ = ddist.init_from_env("cpu")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    B_total, S = args.batch * world, args.seq
+    ids, mask = synthetic_batch(B_total, S, 8008, seed=0xBADB01)
+    lo, hi = ddist.shard_bounds(B_total, world, rank)
+    ctx = RawContext(ids[lo:hi], mask[lo:hi])
+
+    def stub(local, model, mode, step_freq, philox_offset=0, max_len=-1, **kw):  # ids say which rank's counter range produced them
+        b = local.input_ids.shape[0]
+        return torch.full((b, S), philox_offset >> 40, dtype=torch.int64), torch.full((b,), S, dtype=torch.int32)
+
+    def step():
+        return ddist.sample_sharded(ctx, None, args.mode, args.freq, rank=rank, world=world, max_len=S, eos_id=2, global_batch=B_total,
+                                    sample_fn=stub)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_ids, _ = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    owners = [int(out_ids[ddist.shard_bounds(B_total, world, r)[0], 0]) for r in range(world)]
+    assert tuple(out_ids.shape) == (B_total, S) and owners == list(range(world)), owners
+    if rank == 0:
+        print(json.dumps({"metric": "sampled dialogs/sec (whole node, T steps)", "value": round(B_total * args.steps / elapsed, 3), "unit": "dialogs/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic", "valid": False,
+                          "config": {"workload": "launch-path rehearsal on CPU: stub sampler, no kernels (--device cpu)", "global_batch": B_total,
+                                     "seq_len": S, "parallelism": f"dp{world} (batch shard, id all-gather)",
+                                     "world_size_seen": torch.distributed.get_world_size() if world > 1 else 1,
+                                     "backend": torch.distributed.get_backend() if world > 1 else None}}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", default="fp16-sched", choices=["bf16", "fp16", "fp16x2", "fp16-sched", "fp16x3", "bf16x3"],
-                    help="fp16-sched (default): fp16 planes with the precision schedule of didi_amd.model.DEFAULT_SCHEDULE (one MFMA product "
-                         "for t > 0.35 T, the weights' remainder for t > 0.064 T, all three products for the last steps): the cheapest "
+                    help="fp16-sched (default): fp16 planes with the precision schedule of didi_amd.model.DEFAULT_SCHEDULE (ddpm: one MFMA product, "
+                         "cycling through 4 differently rounded weight copies, for t > 0.15 T; the weights' remainder for t > 0.064 T; all three "
+                         "products for the last steps and at least the last 64 calls; euler: two products, then three): the cheapest "
                          "configuration that holds ids >= 99.9 %% and x_t <= 1e-3 over the 2000-call loop at THIS model size; fp16 / fp16x2: "
                          "one / two products throughout (miss the bars at 2000 calls); fp16x3 / bf16x3: fp32-class, three products")
     ap.add_argument("--mode", default="ddpm", choices=["ddpm", "euler"])
@@ -293,7 +397,13 @@ def main():
     ap.add_argument("--preset", default=None, choices=["configs1", "configs2", "configs3", "configs4"],
                     help="BASELINE.json configs[i]: configs1 = the default (ddpm, f=1, 256/GPU); configs2 = 'DDIM 200-step, batch 4096 over "
                          "8 GPUs' = euler, step_freq 10, 512 dialogs/GPU; configs3 = V=50000, seq 84, batch 1024, per-step clamp")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu: rehearsal of the multi-rank launch path over gloo with a stub sampler (no kernels, the line is marked invalid)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: start the ranks ourselves, before anything touches the GPU
+        return spawn_ranks(args.gpus)
+    if args.device == "cpu":
+        return main_rehearsal(args)
     if args.preset == "configs4":  # BASELINE configs[4]: the training step (secondary line; the headline metric is the sampler's)
         return main_training(args)
     workload = "BASELINE configs[1]"
@@ -475,4 +585,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -25,6 +25,8 @@ Extra keyword-only arguments (all optional; defaults reproduce the reference cal
   trace   list      receives the denoiser input x_t of every call (fp32 [B,S,H], on device)
   return_ids        return (ids [B,S] int64, lengths [B] int32) instead of decoded strings
   philox_offset     first Philox counter of this call (didi_amd/dist.py gives every rank a disjoint range)
+  philox_seed       Philox key of the in-kernel noise instead of a draw from torch's global generator (the full-size reference
+                    fixtures of tests/golden/cfg2_* were sampled from this stream: oracle/make_golden.py PhiloxFeed)
   return_x0         return the denoised embeddings x0 [B, S, H] fp32 (what ``classifier`` is applied to, :64,:82) instead of
                     logits / strings: didi_amd/validation.py rounds them with a cross-entropy epilogue
   target_len        reply length S, overriding ``len(range(C)[:max_len])``: lets a batch whose context padding was trimmed
@@ -65,7 +67,8 @@ def _host_arrays(plan, mode):
 
 @torch.no_grad()
 def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, max_len=-1, raw_output=False,
-           skip_special=True, *, noise=None, trace=None, return_ids=False, philox_offset=0, clamp=False, target_len=None, return_x0=False, _prof=None):
+           skip_special=True, *, noise=None, trace=None, return_ids=False, philox_offset=0, philox_seed=None, clamp=False, target_len=None, return_x0=False,
+           _prof=None):
     if mode not in ("ddpm", "euler"):
         raise NotImplementedError(f"No {mode} sampling strategy")
     if not raw_output and not return_ids and not return_x0 and tokenizer is None:
@@ -96,7 +99,7 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
     noise_t = None
     if noise is None:
         # one draw from the global generator -> Philox key: reproducible under torch.manual_seed
-        seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+        seed = int(philox_seed) if philox_seed is not None else int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
     elif isinstance(noise, str):
         if noise != "torch":
             raise ValueError("noise must be None, 'torch' or a tensor")

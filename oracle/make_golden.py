@@ -55,6 +55,8 @@ class RefShapedDiDi(nn.Module):
         self.register_buffer("sigmas", sigmas)
         self.register_buffer("std_0", std_0)
         self.calls = []  # decoder_inputs_embeds of every call, in order
+        self.keep_calls = None  # a set of call indices: record only those (full-size runs: 2000 calls x 3 MB otherwise)
+        self.n_calls = 0
 
     def forward(self, encoder_input_ids=None, encoder_attention_mask=None, decoder_inputs_embeds=None,
                 time_ids=None, context=None):
@@ -64,7 +66,9 @@ class RefShapedDiDi(nn.Module):
             context = self.encoder(input_ids=encoder_input_ids, attention_mask=encoder_attention_mask).last_hidden_state
             if self.encoder_dim != self.decoder_dim:
                 context = self.adapter(context)
-        self.calls.append(decoder_inputs_embeds.detach().clone())
+        if self.keep_calls is None or self.n_calls in self.keep_calls:
+            self.calls.append(decoder_inputs_embeds.detach().clone())
+        self.n_calls += 1
         x = decoder_inputs_embeds + self.time_embeds(time_ids)
         out = self.decoder(inputs_embeds=x, encoder_hidden_states=context,
                            encoder_attention_mask=encoder_attention_mask).last_hidden_state
@@ -359,6 +363,116 @@ def training_cases():
               f"{n_grads} parameter gradients, {len(tap.draws)} draws")
 
 
+CFG2 = dict(vocab=8008, enc_kind="blenderbot", enc_dim=1280, enc_layers=2, enc_heads=32, enc_ffn=5120,
+            dec_dim=768, dec_layers=12, dec_heads=12, dec_ffn=3072, T=2000, schedule="sqrt")
+# (name, mode, step_freq, weights, stored calls): ddpm f=1 is BASELINE configs[1] (what bench.py times), euler f=10 is the
+# "DDIM 200-step" loop of configs[2]; the stored calls bracket where the 16-bit error peaks (calls ~1700-1850 of 2000)
+FULLSIZE = [
+    ("cfg2_ddpm_f1", "ddpm", 1, "random", [0, 1, 2, 200, 600, 1000, 1400, 1700, 1800, 1870, 1950, 1999]),
+    ("cfg2_ddpm_f1_trained_like", "ddpm", 1, "trained_like", [0, 1, 2, 200, 600, 1000, 1400, 1700, 1800, 1870, 1950, 1999]),
+    ("cfg2_euler_f10", "euler", 10, "random", [0, 1, 2, 20, 60, 100, 140, 170, 185, 195, 200]),
+]
+FULLSIZE_B_GPU, FULLSIZE_B_REF, FULLSIZE_B_XT = 48, 16, 8
+FULLSIZE_PHILOX_SEED = 0xBADB01  # configs/train.yaml:1
+
+
+class PhiloxFeed:
+    """Make the reference sampler draw its noise from the product's counter-based stream instead of torch's generator:
+    draw i of a B_ref-dialog run = the first B_ref dialogs' share of draw i of a B_gpu-dialog GPU run (engine.hip: counter =
+    base_offset + i * (B_gpu*S*H/4) + element/4), computed by the numpy restatement oracle/philox.py.  The GPU box can then
+    reproduce the run from (seed, B_gpu) alone -- no noise tensor travels, and the product runs its in-kernel generator, as in
+    bench.py.  Replaces ``torch.randn_like`` and ``Tensor.normal_`` while ``sample`` runs (src/sampling.py:13,54,74,79)."""
+
+    def __init__(self, seed, ctr_per_draw):
+        self.seed, self.ctr_per_draw, self.i = seed, ctr_per_draw, 0
+
+    def _draw(self, shape):
+        from oracle.philox import normal
+        import numpy as np
+
+        n = int(np.prod(shape))
+        t = torch.from_numpy(normal(n, self.seed, self.i * self.ctr_per_draw)).view(*shape)
+        self.i += 1
+        return t
+
+    def __enter__(self):
+        self._randn_like, self._normal_ = torch.randn_like, torch.Tensor.normal_
+        feed = self
+
+        def randn_like(x, *a, **k):
+            return feed._draw(tuple(x.shape)).to(x.dtype)
+
+        def normal_(self_t, mean=0, std=1, **k):
+            assert mean == 0 and std == 1
+            return self_t.copy_(feed._draw(tuple(self_t.shape)))
+
+        torch.randn_like, torch.Tensor.normal_ = randn_like, normal_
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like, torch.Tensor.normal_ = self._randn_like, self._normal_
+
+
+def fullsize_cases(only=None):
+    """(X) The BENCHMARKED model size under the reference sampler: HF ``BertModel`` 12 x 768 decoder + 2 x 1280 Blenderbot encoder
+    holding the seed-1234 synthetic weights (didi_amd.synthetic: what bench.py and the GPU tests build), the imported
+    ``src.sampling.sample``, 16 dialogs, T = 2000.  Stored: final ids and top-2 logit gaps of the 16 dialogs, the final x0
+    (the classifier's input), and the denoiser input x_t of the first 8 dialogs at a dozen calls.  ~40 CPU-minutes per
+    2000-call case on 8 cores."""
+    import time
+
+    sys.path.insert(0, os.path.dirname(OUT))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from golden_util import trained_like
+    from didi_amd.config import DiDiConfig
+    from didi_amd.synthetic import synthetic_batch, synthetic_state_dict
+    from src.sampling import sample
+
+    cfg = DiDiConfig(diffusion_steps=CFG2["T"])
+    Bg, Bo, Bx, C, S, H = FULLSIZE_B_GPU, FULLSIZE_B_REF, FULLSIZE_B_XT, 64, 64, CFG2["dec_dim"]
+    ids, mask = synthetic_batch(Bg, C, cfg.vocab, seed=11)
+    for name, mode, f, weights, keep in FULLSIZE:
+        if only and name not in only:
+            continue
+        sd = synthetic_state_dict(cfg, seed=1234)
+        if weights == "trained_like":
+            sd = trained_like(sd)
+        m = build_model(CFG2, seed=0)
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected, unexpected
+        assert all(("position_ids" in k or "token_type_ids" in k or "word_embeddings" in k or "pooler" in k) for k in missing), missing
+        m.keep_calls, m.n_calls = set(keep), 0
+        m.calls.clear()
+        x0_seen = []
+        hook = m.classifier.register_forward_pre_hook(lambda mod, inp: x0_seen.append(inp[0].detach().clone()))
+        t0 = time.time()
+        orig_forward = m.forward
+
+        def ticking(*a, _orig=orig_forward, **k):
+            if m.n_calls % 50 == 0:
+                print(f"  {name}: call {m.n_calls}  ({time.time() - t0:.0f} s)", flush=True)
+            return _orig(*a, **k)
+
+        m.forward = ticking
+        with PhiloxFeed(FULLSIZE_PHILOX_SEED, Bg * S * H // 4) as feed, torch.no_grad():
+            logits = sample(Ctx(ids[:Bo], mask[:Bo]), m, mode, f, max_len=S, raw_output=True)
+        hook.remove()
+        n_calls = m.n_calls
+        assert n_calls == len(range(cfg.diffusion_steps, 1, -f)) + 1 and len(m.calls) == len(keep) and len(x0_seen) == 1
+        top2 = logits.topk(2, -1).values
+        t = {"in.input_ids": ids, "in.attention_mask": mask, "out.ids": logits.argmax(-1).contiguous(),
+             "out.top2_gap": (top2[..., 0] - top2[..., 1]).contiguous(), "out.x0": x0_seen[0].contiguous()}
+        for k, c in zip(keep, m.calls):
+            t[f"xt.{k}"] = c[:Bx].contiguous()
+        run = dict(mode=mode, step_freq=f, max_len=S, weights=weights, weight_seed=1234, batch_seed=11,
+                   philox_seed=FULLSIZE_PHILOX_SEED, B_gpu=Bg, B_ref=Bo, B_xt=Bx)
+        save_file(t, os.path.join(OUT, name + ".safetensors"),
+                  metadata={"spec": json.dumps(CFG2), "run": json.dumps(run), "weights_sha256": sd_hash(sd), "n_calls": str(n_calls),
+                            "n_noise": str(feed.i), "kept_calls": json.dumps(keep)})
+        print(f"wrote {name}: {n_calls} calls, {feed.i} draws in {time.time() - t0:.0f} s; median top-2 gap "
+              f"{float(t['out.top2_gap'].median()):.3f}, min {float(t['out.top2_gap'].min()):.2e}", flush=True)
+
+
 def main():
     sys.path.insert(0, REF)
     os.makedirs(OUT, exist_ok=True)
@@ -368,6 +482,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "wide":  # add the wide-head encoder case without regenerating the others
         wide_head_cases()
         wide_t5_case()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize":  # the cfg2-sized 2000-call cases (~40 CPU-minutes each); optional names follow
+        torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
+        fullsize_cases(set(sys.argv[2:]) or None)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "train":  # add the training-step cases without regenerating the others
         training_cases()

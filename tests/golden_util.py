@@ -97,3 +97,23 @@ class ListNoise:
 
 def noise_list(tensors, n):
     return [tensors[f"noise.{i}"] for i in range(n)]
+
+
+def trained_like(sd, seed=5):
+    """Outlier features and non-unit scales of the kind trained post-LN decoders show: LayerNorm gammas spread over
+    [0.3, 3] with a few at 8, two hidden units carrying large constant offsets (+-40) through the output-projection biases,
+    attention and FFN weights scaled up (x4) so that softmaxes are peaked and GELU inputs span its whole range."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sd.items():
+        v = v.clone()
+        if k.startswith("decoder.") and k.endswith("LayerNorm.weight"):
+            v = v * torch.exp(torch.empty_like(v).uniform_(-1.2, 1.1, generator=g))
+            v[torch.randint(0, v.numel(), (3,), generator=g)] = 8.0
+        elif k.startswith("decoder.encoder.") and k.endswith("output.dense.bias"):
+            v[5] += 40.0
+            v[17] -= 40.0
+        elif k.startswith("decoder.encoder.") and k.endswith((".query.weight", ".key.weight", "intermediate.dense.weight")):
+            v = v * 4.0
+        out[k] = v
+    return out

@@ -190,3 +190,35 @@ def test_flat_gradient_allreduce_world2_gloo():
     assert _run(_flat_worker, (64 << 20,), 2) == [(0, True, True), (1, True, True)]
     assert _run(_flat_worker, (400,), 2) == [(0, True, True), (1, True, True)]    # 100-float buckets: 10 of them, last = 100 + 8
     assert _run(_flat_worker, (4 * 252,), 2) == [(0, True, True), (1, True, True)]  # remainder 244 + 8 <= 252 + 8: folded into one
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent starts two ranks itself (bench.py spawn_ranks),
+    rank 0 prints ONE JSON line, both ranks took part (world_size_seen 2, gloo), exit code 0.  --device cpu swaps the sampler for a
+    stub: what is rehearsed is the launch path the driver's N > 1 command takes."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--device", "cpu", "--steps", "2", "--warmup", "1", "--batch", "5"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["world_size_seen"] == 2 and res["config"]["backend"] == "gloo"
+    assert res["config"]["global_batch"] == 10 and res["steps"] == 2 and res["valid"] is False
+
+
+def test_bench_spawn_relays_a_failing_rank():
+    """A rank that fails makes the bare `--gpus N` command exit non-zero instead of hanging on the survivors' collectives."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--device", "cpu", "--steps", "1", "--warmup", "0", "--batch", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0

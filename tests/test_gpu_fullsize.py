@@ -93,6 +93,62 @@ def test_cfg2_size_loop_ids_and_xt_vs_oracle(mode, weights):
         del model, trace
 
 
+FULLSIZE_CASES = ["cfg2_ddpm_f1", "cfg2_ddpm_f1_trained_like", "cfg2_euler_f10"]
+
+
+@pytest.mark.parametrize("case", FULLSIZE_CASES)
+def test_cfg2_size_vs_reference_fixture(case):
+    """The BENCHMARKED configuration against the REFERENCE ITSELF: tests/golden/cfg2_*.safetensors hold what the imported
+    ``src.sampling.sample`` (/root/reference/src/sampling.py:38-101) produced in the build container driving HF ``BertModel``
+    (12 x 768, causal + cross-attention) and a 2 x 1280 ``BlenderbotEncoder`` loaded with the seed-1234 synthetic weights, on 16
+    dialogs, with its noise drawn from the product's Philox stream (oracle/make_golden.py ``fullsize``).  cfg2_ddpm_f1 is BASELINE
+    configs[1] as bench.py times it -- ddpm, T = 2000, step_freq = 1: 2000 denoiser calls, 1700 of them one-product fp16 under
+    the 4-way weight dither --, cfg2_ddpm_f1_trained_like the same loop on weights with trained-decoder statistics, cfg2_euler_f10
+    the "DDIM 200-step" loop of configs[2].  The GPU samples 48 dialogs (M = 3072 rows: 256x192 tiles with the fused
+    projection + LayerNorm, bench.py's kernels) with IN-KERNEL noise from the fixture's seed: nothing but the seed travels.
+    Bars (the default precision `fp16-sched`): ids >= 99.9 % of the 1024 stored positions, x_t rel-L2 <= 1e-3 at every stored
+    call (the calls bracket the error's peak near call 1800 of 2000) and for the final x0.  bf16x3 rides along at 3e-4."""
+    from didi_amd.config import DiDiConfig
+    from didi_amd.model import DiDiSampler
+    from didi_amd.sampling import sample
+    from didi_amd.synthetic import synthetic_batch, synthetic_state_dict
+    from golden_util import load_case, sd_hash, trained_like
+
+    t, meta = load_case(case)
+    run, keep = meta["run"], meta["kept_calls"]
+    cfg = DiDiConfig(diffusion_steps=meta["spec"]["T"])
+    sd = synthetic_state_dict(cfg, seed=run["weight_seed"])
+    if run["weights"] == "trained_like":
+        sd = trained_like(sd)
+    assert sd_hash(sd) == meta["weights_sha256"], "the regenerated weights are not the ones the reference run used"
+    Bg, Bo, Bx, S = run["B_gpu"], run["B_ref"], run["B_xt"], run["max_len"]
+    ids, mask = synthetic_batch(Bg, 64, cfg.vocab, seed=run["batch_seed"])
+    assert torch.equal(ids, t["in.input_ids"]) and torch.equal(mask, t["in.attention_mask"])
+    want_ids, gap = t["out.ids"], t["out.top2_gap"]
+    for precision, bar in (("fp16-sched", 1e-3), ("bf16x3", 3e-4)):
+        model = DiDiSampler(sd, cfg, device="cuda", precision=precision)
+        trace = []
+        t0 = time.time()
+        got, _ = sample(_ctx(ids, mask), model, run["mode"], run["step_freq"], max_len=S, return_ids=True, trace=trace,
+                        philox_seed=run["philox_seed"], philox_offset=0)
+        model.check_fault(f"{case} {precision}")
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        assert len(trace) == int(meta["n_calls"])
+        errs = {k: rel_l2(trace[k][:Bx], t[f"xt.{k}"]) for k in keep}
+        x0 = next(iter(model._bufs.values()))["x0"].view(Bg, S, -1)
+        e_x0 = rel_l2(x0[:Bo], t["out.x0"])
+        differ = (got[:Bo].cpu() != want_ids)
+        flips = int(differ.sum())
+        print(f"\n[{case} {precision}] {len(trace)} calls x {Bg} dialogs in {dt:.1f} s; ids differ {flips} of {want_ids.numel()} "
+              f"(reference top-2 gaps there: {[f'{g:.1e}' for g in gap[differ].tolist()]}); final x0 rel-L2 {e_x0:.2e}; x_t rel-L2 "
+              + " ".join(f"{k}:{e:.1e}" for k, e in errs.items()), flush=True)
+        assert max(errs.values()) <= bar and e_x0 <= bar
+        assert 1.0 - flips / want_ids.numel() >= 0.999
+        del model, trace
+        torch.cuda.empty_cache()
+
+
 def test_bench_shape_single_call_full_chip():
     """B = 256, S = C = 64 (bench.py's shape): one denoiser call + rounding in fp16x2, fp16 (the regimes of bench.py's default schedule, one by one) and bf16x3.
     Every output finite, no device fault, and the first 4 dialogs agree with the oracle."""

@@ -23,6 +23,17 @@ from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Tuple
 import torch
 
 
+FAMILIES = ("bert", "blenderbot", "t5")  # the order of the reference's `Modes` enum: the first name found in the base name wins
+
+
+def family_of(base_name: str) -> str:
+    """``get_mode`` (src/diffusion/model.py:22-26): the tokenizer / encoder family a hub model name belongs to."""
+    for fam in FAMILIES:
+        if fam in base_name:
+            return fam
+    raise ValueError(f"Unsupported base name: {base_name}")
+
+
 class Preprocessor:
     """src/data/utils.py:6-23: join the utterances of a dialog and wrap context and reply in bos/eos."""
 
@@ -32,7 +43,10 @@ class Preprocessor:
 
     @classmethod
     def for_tokenizer(cls, tokenizer, family: str):
-        """``family``: "bert" (cls/sep), "blenderbot" (bos/eos) or "t5" ("" / newline / eos), as utils.py:11-18."""
+        """``family``: "bert" (cls/sep), "blenderbot" (bos/eos) or "t5" ("" / newline / eos), as utils.py:11-18; a hub model
+        name is accepted too (``family_of``)."""
+        if family not in FAMILIES:
+            family = family_of(family)
         if family == "bert":
             return cls(tokenizer.cls_token, tokenizer.sep_token)
         if family == "blenderbot":

@@ -372,7 +372,7 @@ FULLSIZE = [
     ("cfg2_ddpm_f1_trained_like", "ddpm", 1, "trained_like", [0, 1, 2, 200, 600, 1000, 1400, 1700, 1800, 1870, 1950, 1999]),
     ("cfg2_euler_f10", "euler", 10, "random", [0, 1, 2, 20, 60, 100, 140, 170, 185, 195, 200]),
 ]
-FULLSIZE_B_GPU, FULLSIZE_B_REF, FULLSIZE_B_XT = 48, 16, 8
+FULLSIZE_B_GPU, FULLSIZE_B_REF, FULLSIZE_B_XT = 48, 16, 4
 FULLSIZE_PHILOX_SEED = 0xBADB01  # configs/train.yaml:1
 
 
@@ -417,7 +417,7 @@ def fullsize_cases(only=None):
     """(X) The BENCHMARKED model size under the reference sampler: HF ``BertModel`` 12 x 768 decoder + 2 x 1280 Blenderbot encoder
     holding the seed-1234 synthetic weights (didi_amd.synthetic: what bench.py and the GPU tests build), the imported
     ``src.sampling.sample``, 16 dialogs, T = 2000.  Stored: final ids and top-2 logit gaps of the 16 dialogs, the final x0
-    (the classifier's input), and the denoiser input x_t of the first 8 dialogs at a dozen calls.  ~40 CPU-minutes per
+    (the classifier's input), and the denoiser input x_t of the first 4 dialogs at a dozen calls.  ~40 CPU-minutes per
     2000-call case on 8 cores."""
     import time
 
@@ -461,7 +461,9 @@ def fullsize_cases(only=None):
         assert n_calls == len(range(cfg.diffusion_steps, 1, -f)) + 1 and len(m.calls) == len(keep) and len(x0_seen) == 1
         top2 = logits.topk(2, -1).values
         t = {"in.input_ids": ids, "in.attention_mask": mask, "out.ids": logits.argmax(-1).contiguous(),
-             "out.top2_gap": (top2[..., 0] - top2[..., 1]).contiguous(), "out.x0": x0_seen[0].contiguous()}
+             "out.top2_gap": (top2[..., 0] - top2[..., 1]).contiguous(), "out.x0": x0_seen[0].contiguous(),
+             # the schedule buffers as a checkpoint would carry them: configure_schedule's last bits differ between host CPUs
+             "w.sigmas": sd["sigmas"].contiguous(), "w.std_0": sd["std_0"].reshape(1).contiguous()}
         for k, c in zip(keep, m.calls):
             t[f"xt.{k}"] = c[:Bx].contiguous()
         run = dict(mode=mode, step_freq=f, max_len=S, weights=weights, weight_seed=1234, batch_seed=11,
@@ -471,6 +473,58 @@ def fullsize_cases(only=None):
                             "n_noise": str(feed.i), "kept_calls": json.dumps(keep)})
         print(f"wrote {name}: {n_calls} calls, {feed.i} draws in {time.time() - t0:.0f} s; median top-2 gap "
               f"{float(t['out.top2_gap'].median()):.3f}, min {float(t['out.top2_gap'].min()):.2e}", flush=True)
+
+
+def preprocessor_cases():
+    """(P) ``Preprocessor`` of /root/reference/src/data/utils.py:6-23 for the three tokenizer families.  Its module cannot be imported
+    here (it imports src.diffusion.model -> lightning, and its constructor fetches a tokenizer from the hub), so the class
+    definition is taken from the reference file's syntax tree at run time -- together with ``Modes`` / ``get_mode`` from
+    src/diffusion/model.py:16-26, which it calls -- and executed as it stands; the only stand-in is the ``AutoTokenizer`` name,
+    whose ``from_pretrained`` returns an object carrying the special-token strings of the family's real tokenizer.  Nothing of
+    the reference's text is stored: the fixture holds inputs and the strings the class returned."""
+    import ast
+    from enum import Enum
+
+    def defs(path, names):
+        tree = ast.parse(open(path).read())
+        keep = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
+        assert len(keep) == len(names), (path, [n.name for n in keep])
+        return compile(ast.Module(body=keep, type_ignores=[]), path, "exec")
+
+    specials = {  # the special-token strings of the hub tokenizers the reference names (configs/train.yaml:3-5)
+        "bert-base-uncased": dict(cls_token="[CLS]", sep_token="[SEP]", bos_token=None, eos_token=None),
+        "facebook/blenderbot-400M-distill": dict(cls_token=None, sep_token=None, bos_token="<s>", eos_token="</s>"),
+        "t5-base": dict(cls_token=None, sep_token=None, bos_token=None, eos_token="</s>"),
+    }
+
+    class Tok:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    class AutoTokenizer:
+        @staticmethod
+        def from_pretrained(name, **kw):
+            return Tok(**specials[name])
+
+    ns = {"Enum": Enum, "AutoTokenizer": AutoTokenizer}
+    exec(defs(os.path.join(REF, "src/diffusion/model.py"), ["Modes", "get_mode"]), ns)
+    exec(defs(os.path.join(REF, "src/data/utils.py"), ["Preprocessor"]), ns)
+    inputs = [("how are you ?", "fine , thanks ."), (["hi", "hello there", "what's up ?"], "not much"), ("", ""), (["only one"], "x"),
+              ([], "reply to nothing")]
+    out = []
+    for name in specials:
+        p = ns["Preprocessor"](name)
+        out.append({"base_name": name, "family": ns["get_mode"](name).value, "tokens": specials[name],
+                    "bos": p.bos, "eos": p.eos, "sep": p.sep,
+                    "cases": [{"src": s_, "trg": t_, "out": list(p(s_, t_))} for s_, t_ in inputs]})
+    bad = None
+    try:
+        ns["get_mode"]("gpt2")
+    except ValueError as e:
+        bad = str(e)
+    with open(os.path.join(OUT, "preprocessor.json"), "w") as f:
+        json.dump({"families": out, "unsupported": {"base_name": "gpt2", "error": bad}}, f, indent=1)
+    print("wrote preprocessor.json:", [(o["family"], o["bos"], o["eos"], o["sep"]) for o in out])
 
 
 def main():
@@ -486,6 +540,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":  # the cfg2-sized 2000-call cases (~40 CPU-minutes each); optional names follow
         torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
         fullsize_cases(set(sys.argv[2:]) or None)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "preproc":
+        preprocessor_cases()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "train":  # add the training-step cases without regenerating the others
         training_cases()

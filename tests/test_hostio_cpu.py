@@ -136,3 +136,34 @@ def test_sample_file_surfaces_worker_and_sampler_errors(tmp_path):
     w.put(5, "a", "b", "c")  # a hole before record 5
     with pytest.raises(RuntimeError, match="never written"):
         w.close()
+
+
+def test_preprocessor_against_the_reference_class():
+    """tests/golden/preprocessor.json holds what the REFERENCE's ``Preprocessor`` (src/data/utils.py:6-23, executed from the
+    reference file by oracle/make_golden.py preproc) returned for the three tokenizer families: the same special-token strings
+    in, the same (context, reply) strings out -- utterance lists joined by the family's separator, empty strings, an empty
+    list -- and ``get_mode``'s error for a name of no family."""
+    import json
+    import os
+
+    import pytest
+
+    from didi_amd import hostio
+
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "preprocessor.json")))
+    assert len(fx["families"]) == 3
+
+    class Tok:
+        pass
+
+    for fam in fx["families"]:
+        tok = Tok()
+        tok.__dict__.update(fam["tokens"])
+        assert hostio.family_of(fam["base_name"]) == fam["family"]
+        for p in (hostio.Preprocessor.for_tokenizer(tok, fam["family"]), hostio.Preprocessor.for_tokenizer(tok, fam["base_name"])):
+            assert (p.bos, p.eos, p.sep) == (fam["bos"], fam["eos"], fam["sep"])
+            for c in fam["cases"]:
+                assert list(p(c["src"], c["trg"])) == c["out"], (fam["family"], c)
+    with pytest.raises(ValueError) as e:
+        hostio.family_of(fx["unsupported"]["base_name"])
+    assert str(e.value) == fx["unsupported"]["error"]

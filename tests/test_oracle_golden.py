@@ -151,3 +151,52 @@ def test_training_step_oracle_matches_reference_fixture(name):
     for k, g in want.items():
         assert k in grads, k
         assert rel_l2(grads[k], g) <= 2e-5 or (g.norm() < 1e-12 and grads[k].norm() < 1e-9), (k, rel_l2(grads[k], g))
+
+
+@pytest.mark.parametrize("case", ["cfg2_ddpm_f1", "cfg2_ddpm_f1_trained_like", "cfg2_euler_f10"])
+def test_oracle_against_the_full_size_reference_fixture(case):
+    """The oracle at the BENCHMARKED model size (12 x 768 decoder, 2 x 1280 encoder): its first three denoiser inputs for two
+    dialogs against what the reference sampler + HF modules produced (tests/golden/cfg2_*, oracle/make_golden.py fullsize), on
+    the same Philox-fed noise.  x_t of call 2 has been through the encoder, the adapter, the hoisted cross-attention and two
+    whole decoder passes; the fixture's remaining ~2000 calls are the GPU test's (tests/test_gpu_fullsize.py)."""
+    import numpy as np
+
+    from didi_amd.config import DiDiConfig
+    from didi_amd.synthetic import synthetic_batch, synthetic_state_dict
+    from golden_util import sd_hash, trained_like
+    from oracle.philox import normal
+
+    t, meta = load_case(case)
+    run = meta["run"]
+    cfg = DiDiConfig(diffusion_steps=meta["spec"]["T"])
+    sd = synthetic_state_dict(cfg, seed=run["weight_seed"])
+    if run["weights"] == "trained_like":
+        sd = trained_like(sd)
+    sd["sigmas"], sd["std_0"] = t["w.sigmas"], t["w.std_0"].reshape(())  # buffers of the checkpoint (their last bits vary with the host CPU)
+    assert sd_hash(sd) == meta["weights_sha256"]
+    ids, mask = synthetic_batch(run["B_gpu"], 64, cfg.vocab, seed=run["batch_seed"])
+    assert torch.equal(ids, t["in.input_ids"]) and torch.equal(mask, t["in.attention_mask"])
+    Bo, S, H = 2, run["max_len"], cfg.dec_dim
+    per_draw = run["B_gpu"] * S * H // 4
+
+    class Stop(Exception):
+        pass
+
+    class Feed:
+        i = 0
+
+        def __call__(self, shape):
+            if self.i == 4:
+                raise Stop
+            z = torch.from_numpy(normal(int(np.prod(shape)), run["philox_seed"], self.i * per_draw)).view(*shape)
+            self.i += 1
+            return z
+
+    trace = []
+    with pytest.raises(Stop):
+        sample(Context(ids[:Bo], mask[:Bo]), OracleDiDi(sd, config_to_oracle_config(cfg)), run["mode"], run["step_freq"], max_len=S,
+               raw_output=True, noise_source=Feed(), trace=trace)
+    assert len(trace) >= 3
+    errs = [rel_l2(trace[k], t[f"xt.{k}"][:Bo]) for k in range(3)]
+    print(f"\n[{case}] oracle vs reference x_t rel-L2, calls 0-2: " + " ".join(f"{e:.2e}" for e in errs))
+    assert max(errs) <= 1e-5

@@ -86,7 +86,8 @@ class _Classifier:
 
 
 class DiDiSampler:
-    def __init__(self, state_dict, cfg: DiDiConfig, device="cuda", precision="bf16x3", schedule=None, tail_calls=None, weight_dither=None):
+    def __init__(self, state_dict, cfg: DiDiConfig, device="cuda", precision="bf16x3", schedule=None, tail_calls=None, weight_dither=None,
+                 encoder_only=False):
         """``precision``: bf16 | fp16 (one MFMA product), fp16x2 (weights with their remainder), bf16x3 (fp32-class), or
         "fp16-sched": fp16 planes with the default precision schedule ``DEFAULT_SCHEDULE``.
         ``schedule``: precision schedule of ``sample`` over the TIMESTEP of each denoiser call, a tuple of (t_above, precision)
@@ -96,7 +97,9 @@ class DiDiSampler:
         that precision ("fp16-sched" defaults to ``DEFAULT_TAIL_CALLS``; an explicit schedule to none).
         ``weight_dither``: P > 1 keeps P differently rounded fp16 copies of the per-call GEMM weights and cycles the one-product
         calls of a loop through them (``_build_weight_variants``); fp16 planes only ("fp16-sched" defaults to
-        ``DEFAULT_WEIGHT_DITHER``, everything else to none)."""
+        ``DEFAULT_WEIGHT_DITHER``, everything else to none).
+        ``encoder_only``: build the context encoder (+ adapter) and the schedule buffers only -- what the trainer's frozen part
+        needs (didi_amd/trainer.py); the decoder, embedding and classifier planes are not allocated and sampling is refused."""
         schedule_euler = None
         if precision == "fp16-sched":
             schedule_euler = None if schedule else DEFAULT_SCHEDULE_EULER  # an explicit schedule is used for both samplers
@@ -140,12 +143,14 @@ class DiDiSampler:
         self.sampling_mode, self.step_freq, self.noise_factor = cfg.sampling_mode, cfg.step_freq, cfg.noise_factor
         self.s_churn, self.s_tmin, self.s_tmax = cfg.s_churn, cfg.s_tmin, cfg.s_tmax
         self.encoder_dim, self.decoder_dim, self.pad_idx = cfg.enc_dim, cfg.dec_dim, cfg.pad_idx
-        self.emb = _Embedding(f("emb.weight"))
-        self.time_embeds = _Embedding(f("time_embeds.weight"))
-        cls_w = self.emb.weight if cfg.tie_weights else f("classifier.weight")
+        self.encoder_only = bool(encoder_only)
         self._pd = ops.plane_dtype(precision)  # decoder + classifier planes; the encoder side stays bf16x3
-        self._cls = _Planes(cls_w, None, dev, self._pd)
-        self.classifier = _Classifier(self._cls, cls_w, self)
+        if not self.encoder_only:
+            self.emb = _Embedding(f("emb.weight"))
+            self.time_embeds = _Embedding(f("time_embeds.weight"))
+            cls_w = self.emb.weight if cfg.tie_weights else f("classifier.weight")
+            self._cls = _Planes(cls_w, None, dev, self._pd)
+            self.classifier = _Classifier(self._cls, cls_w, self)
         if "sigmas" in sd:
             self._sigmas_host = sd["sigmas"].detach().float().cpu()
         else:
@@ -153,7 +158,8 @@ class DiDiSampler:
         self.sigmas = self._sigmas_host.to(dev)
         # std_0 = sqrt(beta_0) (configure_schedule's second value; model.py:125-127): read by the training step's get_x0
         self.std_0 = float(sd["std_0"]) if "std_0" in sd else float(configure_schedule(cfg.diffusion_steps, cfg.schedule)[1])
-        self._build_decoder(sd, f)
+        if not self.encoder_only:
+            self._build_decoder(sd, f)
         self._build_encoder(sd, f)
         self._bufs = {}
         self._ctx_key = None
@@ -441,6 +447,8 @@ class DiDiSampler:
         return x0_hi, (x0_lo if rp in ("bf16x3", "fp16x3") else None), rp
 
     def buffers(self, B, S, Cn):
+        if self.encoder_only:
+            raise RuntimeError("this DiDiSampler was built with encoder_only=True: it has no decoder to sample with")
         key = (B, S, Cn)
         b = self._bufs.get(key)
         if b is None:

@@ -65,13 +65,19 @@ class DiDiTrainer:
     forward and backward; the frozen encoder always runs bf16x3."""
 
     def __init__(self, state_dict, cfg, device="cuda", precision="bf16x3", anchor_loss=False, noise_factor=1.0, opt_kwargs=None,
-                 gradient_clip_val=1.0, hidden_dropout=0.0, attention_dropout=0.0):
+                 gradient_clip_val=1.0, hidden_dropout=0.1, attention_dropout=0.1, freeze_encoder=True):
+        """``hidden_dropout`` / ``attention_dropout``: the decoder's ``hidden_dropout_prob`` / ``attention_probs_dropout_prob``;
+        the defaults are what the reference trains with (configs/train.yaml:22-23); the gradient fixtures pass 0.0 explicitly.
+        ``freeze_encoder``: only True is built (configs/train.yaml:19 and configs/reddit_pretrain.yaml both freeze it)."""
+        if not freeze_encoder:
+            raise NotImplementedError("freeze_encoder=False (src/diffusion/model.py:112-115,184-188 back-propagates into the context "
+                                      "encoder) is not built: the backward stops at the adapter input; both shipped configs freeze the encoder")
         self.cfg, self.device, self.precision = cfg, torch.device(device), precision
         self.hidden_dropout, self.attention_dropout = float(hidden_dropout), float(attention_dropout)
         self.anchor_loss, self.noise_factor = bool(anchor_loss), float(noise_factor)
         self.opt = dict(DEFAULT_OPT, **(opt_kwargs or {}))
         self.clip = gradient_clip_val
-        self.frozen = DiDiSampler(state_dict, cfg, device=device, precision="bf16x3")  # context encoder, schedule buffers
+        self.frozen = DiDiSampler(state_dict, cfg, device=device, precision="bf16x3", encoder_only=True)  # context encoder, schedule buffers
         self.sigmas, self.std_0, self.T = self.frozen.sigmas, self.frozen.std_0, cfg.diffusion_steps
         self._pd = ops.plane_dtype(precision)
         self._state_extra = {k: v for k, v in state_dict.items() if k.startswith("encoder.") or k in ("sigmas", "std_0")
@@ -148,8 +154,59 @@ class DiDiTrainer:
         return sd
 
     def sampler(self, **kw):
-        """A DiDiSampler on the current weights (validation_step's ``sample``)."""
+        """A DiDiSampler on the current weights (validation_step's ``sample``).  Default precision bf16x3 (fp32-class, as the
+        reference validates in fp32); pass precision="fp16-sched" for the throughput default of bench.py."""
         return DiDiSampler(self.state_dict(), self.cfg, device=self.device, **kw)
+
+    # ------------------------------------------------------------------ checkpoint / resume (src/training.py:27-33,47)
+    CKPT_KEY = "didi_amd_trainer"
+
+    def save_checkpoint(self, path):
+        """What Lightning's ``ModelCheckpoint`` writes every ``save_interval`` steps (src/training.py:27-33), as plain tensors
+        and numbers only -- ``torch.load(weights_only=True)`` and didi_amd.checkpoint.load_state read it: ``state_dict`` in the
+        reference's key layout (so the file loads into ``DiDiSampler`` / ``load_lightning_checkpoint`` like a reference
+        checkpoint), ``global_step``, plain ``hyper_parameters``, and under ``didi_amd_trainer`` what a resume needs beyond the
+        weights: AdamW's two moments per parameter name, the step count (it drives the LR lambda and the bias correction),
+        ``opt_kwargs``, precision, dropout rates, clip value.  Lightning's own ``optimizer_states`` / ``lr_schedulers`` layout
+        (param-group indices instead of names) is not written: DESIGN.md section 8."""
+        cfg = self.cfg
+        torch.save({
+            "state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()},
+            "global_step": int(self.step_count),
+            "hyper_parameters": {"diffusion_steps": cfg.diffusion_steps, "schedule": cfg.schedule, "step_freq": cfg.step_freq,
+                                 "sampling_mode": cfg.sampling_mode, "tie_weights": bool(cfg.tie_weights), "anchor_loss": self.anchor_loss,
+                                 "noise_factor": self.noise_factor},
+            self.CKPT_KEY: {"exp_avg": {k: v.detach().cpu() for k, v in self.m.items()},
+                            "exp_avg_sq": {k: v.detach().cpu() for k, v in self.v.items()},
+                            "step_count": int(self.step_count), "opt_kwargs": dict(self.opt), "precision": self.precision,
+                            "hidden_dropout": self.hidden_dropout, "attention_dropout": self.attention_dropout,
+                            "gradient_clip_val": self.clip},
+        }, path)
+
+    def load_checkpoint(self, path):
+        """Resume from ``save_checkpoint``'s file (``trainer.fit(ckpt_path=resume)``, src/training.py:47): weights, both AdamW
+        moments and the step count are restored in place, so the next ``training_step`` is the one an uninterrupted run would
+        have taken.  The optimiser settings in the file must be the trainer's (a resumed run that silently changed its LR
+        schedule would not be a resume)."""
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        st = ck.get(self.CKPT_KEY)
+        if st is None:
+            raise ValueError(f"{path}: no '{self.CKPT_KEY}' section (a weights-only checkpoint cannot resume an optimiser)")
+        if dict(st["opt_kwargs"]) != dict(self.opt) or st["precision"] != self.precision:
+            raise ValueError(f"{path}: saved with opt_kwargs {st['opt_kwargs']} / precision {st['precision']}, this trainer has {self.opt} / {self.precision}")
+        sd = ck["state_dict"]
+        missing = [k for k in self.params if k not in sd or k not in st["exp_avg"] or k not in st["exp_avg_sq"]]
+        if missing:
+            raise ValueError(f"{path}: missing {missing[:4]}...")
+        for k, p_ in self.params.items():
+            if tuple(sd[k].shape) != tuple(p_.shape):
+                raise ValueError(f"{path}: {k} has shape {tuple(sd[k].shape)}, expected {tuple(p_.shape)}")
+            p_.copy_(sd[k])
+            self.m[k].copy_(st["exp_avg"][k])
+            self.v[k].copy_(st["exp_avg_sq"][k])
+        self.step_count = int(st["step_count"])
+        self.refresh_planes()
+        return self
 
     # ------------------------------------------------------------------ forward + backward
     def _linear(self, w, a_hi, a_lo, **kw):

@@ -1,4 +1,9 @@
-"""``DiDi.training_step`` on the HIP path: forward + losses, and the first backward pieces.
+"""``DiDi.training_step`` on the HIP path, FORWARD ONLY: the loss values of a step from a ``DiDiSampler``.
+
+The whole step -- this forward with its activations kept, the hand-written backward through the decoder, the gradient all-reduce,
+clipping and AdamW -- is ``didi_amd.trainer.DiDiTrainer``; this module is the light path for callers that want the five logged
+scalars of a batch without training (validation-time loss, the parity tests of the noising and the loss terms) plus
+``metric_message``, the one fp32 [5] message both paths reduce over ranks.
 
 Reference: src/diffusion/model.py:200-243 (``training_step``), :62-63 (``flat_mean``), src/diffusion/utils.py:24-40 (``get_x0``,
 ``get_diffusion_variables``), src/metrics.py:91-93 (``calculate_batch_ce``).  What runs where:
@@ -9,9 +14,7 @@ Reference: src/diffusion/model.py:200-243 (``training_step``), :62-63 (``flat_me
 Reproduced as written: the mse's ``torch.where(t == 1, a, b)`` broadcasts ``t`` [B, 1] against per-dialog means [B] to [B, B], so
 mse = p mean(a) + (1 - p) mean(b) with p the share of dialogs at t == 1; ``t_T`` averages over ALL elements (padding counts in
 the denominator); a third normal draw (model.py:229) is consumed and discarded, so the generator ends where the reference's does.
-Backward this round: the loss gradient with respect to x_0_hat, LayerNorm backward and the Linear backward (dgrad, wgrad, bias)
-on the MFMA GEMM -- checked one at a time against the autograd values in tests/golden/train_tiny_*.  The chained backward through
-attention and the optimiser step are the next round's.
+``mse_backward`` is the loss gradient with respect to x_0_hat alone (checked against autograd in tests/golden/train_tiny_*).
 """
 import torch
 

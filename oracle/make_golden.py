@@ -467,7 +467,7 @@ def fullsize_cases(only=None):
         for k, c in zip(keep, m.calls):
             t[f"xt.{k}"] = c[:Bx].contiguous()
         run = dict(mode=mode, step_freq=f, max_len=S, weights=weights, weight_seed=1234, batch_seed=11,
-                   philox_seed=FULLSIZE_PHILOX_SEED, B_gpu=Bg, B_ref=Bo, B_xt=Bx)
+                   philox_seed=FULLSIZE_PHILOX_SEED, B_gpu=Bg, B_ref=Bo, B_xt=Bx, flush_denormal=True)
         save_file(t, os.path.join(OUT, name + ".safetensors"),
                   metadata={"spec": json.dumps(CFG2), "run": json.dumps(run), "weights_sha256": sd_hash(sd), "n_calls": str(n_calls),
                             "n_noise": str(feed.i), "kept_calls": json.dumps(keep)})
@@ -539,6 +539,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":  # the cfg2-sized 2000-call cases (~40 CPU-minutes each); optional names follow
         torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
+        # x86 runs subnormal operands through microcode: from call ~600 of the ddpm loop on, softmax tails / GELU tails that
+        # small made every decoder call 8x slower (27 s -> 224 s per 50 calls).  Flushing them moves values by < 1.2e-38 absolute.
+        torch.set_flush_denormal(True)
         fullsize_cases(set(sys.argv[2:]) or None)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "preproc":

@@ -174,6 +174,8 @@ def _trainer(name, precision="bf16x3", **kw):
     t, meta = load_case(name)
     w = weights_of(load_case("tiny_weights")[0])
     run = meta["run"]
+    kw.setdefault("hidden_dropout", 0.0)  # the gradient fixtures were generated without dropout (the trainer's default is the
+    kw.setdefault("attention_dropout", 0.0)  # reference's 0.1 / 0.1, configs/train.yaml:22-23)
     tr = DiDiTrainer(w, spec_to_config(meta["spec"]), device="cuda", precision=precision, anchor_loss=run["anchor_loss"],
                      noise_factor=run["noise_factor"], **kw)
     ctx = RawContext(t["in.input_ids"].cuda(), t["in.attention_mask"].cuda())
@@ -419,3 +421,59 @@ def test_overlapped_reducer_covers_every_gradient_once(precision):
     for k, g_ in out["grads"].items():  # the caller's dict now views the reduced buffer
         off = tr._offsets[k]
         assert g_.data_ptr() == base + 4 * off and tuple(g_.shape) == tuple(tr.params[k].shape)
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_save_and_resume_is_bit_identical_to_an_uninterrupted_run(tmp_path, dropout):
+    """Checkpoint / resume (src/training.py:27-33,47: ModelCheckpoint every save_interval steps, trainer.fit(ckpt_path=resume)):
+    three steps, save, then a FRESH trainer built from the original weights loads the file and takes step four -- parameters,
+    both AdamW moments, the step count (LR lambda, bias correction) and the step's loss must equal, bit for bit, those of a
+    trainer that took the four steps without interruption.  The file is plain tensors: torch.load(weights_only=True) reads it,
+    and it loads into a DiDiSampler like a reference checkpoint."""
+    from didi_amd.checkpoint import load_lightning_checkpoint
+
+    optk = dict(lr=3e-3, warmup_steps=2, decay_range=10, min_lr=1e-4, scheduler="linear")
+    kw = dict(opt_kwargs=optk, hidden_dropout=dropout, attention_dropout=dropout)
+    t, meta, w, a, ctx, tgt = _trainer("train_tiny_plain", **kw)
+    _, _, _, b, _, _ = _trainer("train_tiny_plain", **kw)
+
+    def step(tr, k):
+        torch.manual_seed(100 + k)  # Philox keys of the noise, the timesteps and the dropout masks come from the global generator
+        return tr.training_step(ctx, tgt)
+
+    for k in range(3):
+        step(a, k)
+        step(b, k)
+    path = tmp_path / "step_3.ckpt"
+    b.save_checkpoint(path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert ck["global_step"] == 3 and set(ck["didi_amd_trainer"]["exp_avg"]) == set(b.params)
+    _, _, _, c, _, _ = _trainer("train_tiny_plain", **kw)  # a restart: original weights, zero moments, step 0
+    c.load_checkpoint(path)
+    assert c.step_count == 3
+    oa, oc = step(a, 3), step(c, 3)
+    assert torch.equal(oa["metrics"], oc["metrics"]) and torch.equal(oa["grad_norm"], oc["grad_norm"])
+    assert torch.equal(a._flat_p, c._flat_p) and torch.equal(a._flat_m, c._flat_m) and torch.equal(a._flat_v, c._flat_v)
+    assert a.step_count == c.step_count == 4
+    # without the optimiser state the run does NOT continue: same weights, zero moments, step 0 -> another step four
+    _, _, _, d, _, _ = _trainer("train_tiny_plain", **kw)
+    for k_, p_ in d.params.items():
+        p_.copy_(ck["state_dict"][k_])
+    d.refresh_planes()
+    step(d, 3)
+    assert not torch.equal(a._flat_p, d._flat_p)
+    # mismatched optimiser settings are refused; the file is also a sampler checkpoint in the reference's key layout
+    _, _, _, e, _, _ = _trainer("train_tiny_plain", opt_kwargs=dict(optk, lr=1e-3))
+    with pytest.raises(ValueError):
+        e.load_checkpoint(path)
+    cfg = spec_to_config(meta["spec"])
+    smp = load_lightning_checkpoint(path, device="cuda", precision="bf16x3", dec_heads=cfg.dec_heads, enc_heads=cfg.enc_heads)
+    assert torch.equal(smp.emb.weight, b.params["emb.weight"])
+
+
+def test_unfrozen_encoder_is_refused():
+    from didi_amd.trainer import DiDiTrainer
+
+    _, meta = load_case("train_tiny_plain")
+    with pytest.raises(NotImplementedError):
+        DiDiTrainer(weights_of(load_case("tiny_weights")[0]), spec_to_config(meta["spec"]), device="cuda", freeze_encoder=False)

@@ -24,7 +24,7 @@ ACT_NONE, ACT_GELU, ACT_TANH, ACT_RELU, ACT_GELU_NEW = 0, 1, 2, 3, 4
 STEP_NONE, STEP_INIT, STEP_DDPM, STEP_EULER = 0, 1, 2, 3
 ERR_FAULT = -5
 FAULT_LN_EXCHANGE, FAULT_FP16_RANGE = 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 # didi_set_option keys (tuning switches for A/B runs; defaults = production path)
 OPTIONS = {"GEMM_LN": 0, "GEMM_SMALL": 1, "GEMM_BIG": 2, "GEMM_PP": 3, "GEMM_MT": 4, "BIG_MIN_M": 5, "SMALL_MAX_M": 6, "X2_GEMMS": 7}
 
@@ -38,7 +38,7 @@ class StepArgs(C.Structure):
         ("x_out", C.c_void_p), ("xin_out", C.c_void_p),
         ("time_embeds", C.c_void_p), ("t", C.c_int), ("time_idx", C.c_void_p),
         ("pos_emb", C.c_void_p), ("tok_type0", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
-        ("ln_eps", C.c_float), ("h_hi", C.c_void_p), ("h_lo", C.c_void_p), ("plane_format", C.c_int),
+        ("ln_eps", C.c_float), ("h_hi", C.c_void_p), ("h_lo", C.c_void_p), ("plane_format", C.c_int), ("act_dither", C.c_int),
     ]
 
 
@@ -50,7 +50,7 @@ class GemmArgs(C.Structure):
         ("bias", C.c_void_p), ("act", C.c_int),
         ("R_f32", C.c_void_p), ("R_hi", C.c_void_p), ("R_lo", C.c_void_p), ("ldr", C.c_int),
         ("C_f32", C.c_void_p), ("C_hi", C.c_void_p), ("C_lo", C.c_void_p), ("ldc", C.c_int),
-        ("fault", C.c_void_p),
+        ("fault", C.c_void_p), ("act_dither", C.c_int),
     ]
 
 
@@ -62,7 +62,7 @@ class AttnArgs(C.Structure):
         ("K_hi", C.c_void_p), ("K_lo", C.c_void_p), ("ldk", C.c_int),
         ("V_hi", C.c_void_p), ("V_lo", C.c_void_p), ("ldv", C.c_int),
         ("O_hi", C.c_void_p), ("O_lo", C.c_void_p), ("ldo", C.c_int),
-        ("scale", C.c_float), ("pos_bias", C.c_void_p), ("key_count", C.c_void_p),
+        ("scale", C.c_float), ("pos_bias", C.c_void_p), ("key_count", C.c_void_p), ("act_dither", C.c_int),
     ]
 
 
@@ -104,7 +104,7 @@ class ForwardArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("x0_f32", C.c_void_p), ("x0_hi", C.c_void_p), ("x0_lo", C.c_void_p),
         ("prof_events_host", C.POINTER(C.c_void_p)), ("prof_capacity", C.c_int), ("prof_used_host", C.POINTER(C.c_int)),
-        ("fault", C.c_void_p),
+        ("fault", C.c_void_p), ("act_dither", C.c_int),
     ]
 
 
@@ -120,7 +120,7 @@ class SampleArgs(C.Structure):
         ("ids64", C.c_void_p),
         ("prof_calls_host", C.POINTER(C.c_int)), ("n_prof_calls", C.c_int), ("prof_events_host", C.POINTER(C.c_void_p)), ("prof_capacity", C.c_int),
         ("prof_used_host", C.POINTER(C.c_int)), ("clamp_emb", C.c_void_p), ("fault", C.c_void_p),
-        ("precision_host", C.POINTER(C.c_int)), ("dec_variants_host", C.POINTER(C.c_void_p)), ("n_variants", C.c_int),
+        ("precision_host", C.POINTER(C.c_int)), ("dec_variants_host", C.POINTER(C.c_void_p)), ("n_variants", C.c_int), ("act_dither", C.c_int),
     ]
 
 

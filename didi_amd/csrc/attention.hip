@@ -41,6 +41,7 @@ struct AttnParams {
     int SP, CP;  // padded lengths: SP % 16 == 0, CP % 32 == 0
     int d;       // true head dim (multiple of 8, <= D); columns d..D-1 are zero padding in LDS
     int nh;      // heads per workgroup (divides heads)
+    int dither;  // one-product fp16: rounding dither of the probability and output planes (common.hpp f16x2_dither), 0 = RNE
 };
 
 typedef short v4s __attribute__((ext_vector_type(4)));
@@ -226,19 +227,31 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
             //      k-step s, element e: key 32*s + 16*(e>>2) + 4*lg + (e&3).  Scores carry log2(e): one
             //      v_exp_f32 per probability; exp2(-inf) = 0 covers padding keys and absent tiles.
             v8s ph[3], pl[3];
+            const int dith = NPASS == 1 && F16 ? p.dither : 0;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
                 ph[s] = v8s{0, 0, 0, 0, 0, 0, 0, 0};
                 pl[s] = v8s{0, 0, 0, 0, 0, 0, 0, 0};
                 if (s < nks) {
+                    if (dith) {  // one-product fp16 call of a dithered loop: two probabilities per v_cvt_pkrtz
+                        float pr[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float pr = __builtin_amdgcn_exp2f(sc[2 * s + (e >> 2)][e & 3] - rmax);
-                        rsum += pr;
-                        u16 h, l;
-                        split2(pr, h, l, F16);
-                        ph[s][e] = (short)h;
-                        pl[s][e] = (short)l;
+                        for (int e = 0; e < 8; ++e) {
+                            pr[e] = __builtin_amdgcn_exp2f(sc[2 * s + (e >> 2)][e & 3] - rmax);
+                            rsum += pr[e];
+                        }
+                        const uint2 a0 = pack4_hi_dither(pr, dith), a1 = pack4_hi_dither(pr + 4, dith);
+                        ph[s] = __builtin_bit_cast(v8s, make_uint4(a0.x, a0.y, a1.x, a1.y));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float pr = __builtin_amdgcn_exp2f(sc[2 * s + (e >> 2)][e & 3] - rmax);
+                            rsum += pr;
+                            u16 h, l;
+                            split2(pr, h, l, F16);
+                            ph[s][e] = (short)h;
+                            pl[s][e] = (short)l;
+                        }
                     }
                 }
             }
@@ -278,7 +291,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
                         *reinterpret_cast<uint2*>(oh + off) = h2;
                         *reinterpret_cast<uint2*>(ol + off) = l2;
                     } else {
-                        *reinterpret_cast<uint2*>(oh + off) = pack4_hi(o, F16);
+                        *reinterpret_cast<uint2*>(oh + off) = dith ? pack4_hi_dither(o, dith) : pack4_hi(o, F16);
                     }
                 }
             }
@@ -325,6 +338,8 @@ extern "C" int didi_attention(const didi_attn_args* a, void* stream) {
     p.K[0] = a->K_hi; p.K[1] = a->K_lo; p.ldk = a->ldk;
     p.V[0] = a->V_hi; p.V[1] = a->V_lo; p.ldv = a->ldv;
     p.O[0] = a->O_hi; p.O[1] = x3 ? a->O_lo : nullptr; p.ldo = a->ldo;
+    DIDI_CHECK_ARG(a->act_dither >= 0 && a->act_dither < 8192);
+    p.dither = a->act_dither;
     p.SP = (a->Sq + 15) / 16 * 16;
     p.CP = (a->Sk + 31) / 32 * 32;
     const size_t lds = attn_lds_bytes(DP, x3 ? 2 : 1, p.CP);  // <= 48.4 KiB: 3-4 workgroups per CU

@@ -53,6 +53,32 @@ __device__ __forceinline__ float join2(u16 hi, u16 lo, int f16 = 0) {
     return f16 ? f16_to_f32(hi) + f16_to_f32(lo) : bf16_to_f32(hi) + bf16_to_f32(lo);
 }
 
+// ---- ordered rounding dither of fp16 ACTIVATION planes (didi_*_args.act_dither) -------------------------------------------
+// Plain RNE is a fixed function of the value: in the late calls of a sampling loop, where consecutive denoiser inputs are nearly
+// identical, every call rounds every activation the same way and the errors add up coherently over the loop (DESIGN.md
+// section 2), exactly as a once-rounded weight does.  With d != 0 the hi plane is instead TRUNCATED after adding d / 8192 of an
+// fp16 ulp to the magnitude (d in units of the fp32 mantissa's last place: the 13 bits fp16 drops); a loop passes
+// d = 1024, 3072, 5120, 7168 in turn, so over four consecutive calls a static value is rounded down 1..4 times in proportion
+// to its remainder and the MEAN of its four roundings is within ulp / 8 of it (plain RNE: ulp / 2, always the same side).
+// One integer add per value; the conversion is v_cvt_pkrtz_f16_f32 (two values per instruction, overflow saturates to
+// +-65504 by construction).  Zero stays zero (0 + d is an fp32 subnormal), NaN stays NaN; +-inf would become NaN: values
+// reach these conversions through the range-checked epilogues only.  The remainder plane stays lo = rne16(x - hi).
+__device__ __forceinline__ uint32_t f16x2_dither(float a, float b, int d) {
+    const float a_ = __builtin_bit_cast(float, __builtin_bit_cast(int, a) + d), b_ = __builtin_bit_cast(float, __builtin_bit_cast(int, b) + d);
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a_, b_));
+}
+__device__ __forceinline__ uint2 pack4_hi_dither(const float v[4], int d) {
+    return make_uint2(f16x2_dither(v[0], v[1], d), f16x2_dither(v[2], v[3], d));
+}
+__device__ __forceinline__ void split4_dither(const float v[4], uint2& hi, uint2& lo, int d) {
+    hi = pack4_hi_dither(v, d);
+    const u16 h[4] = {(u16)(hi.x & 0xffff), (u16)(hi.x >> 16), (u16)(hi.y & 0xffff), (u16)(hi.y >> 16)};
+    u16 l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l[i] = f16_bits(v[i] - f16_to_f32(h[i]));
+    lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+}
+
 // 4 consecutive values -> two 8-byte packs (hi plane, lo plane)
 __device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo, int f16 = 0) {
     u16 h[4], l[4];

@@ -60,7 +60,7 @@ extern "C" int didi_split_fp16(const float* src, uint16_t* hi, uint16_t* lo, siz
 // ------------------------------------------------------------------ LayerNorm tail shared by both row kernels
 template <int MAXV>
 __device__ __forceinline__ void ln_row_store(float (&v)[MAXV][4], int lane, int H, size_t row_off, const float* gamma,
-                                             const float* beta, float eps, u16* y_hi, u16* y_lo, float* y_f32, int f16) {
+                                             const float* beta, float eps, u16* y_hi, u16* y_lo, float* y_f32, int f16, int dith = 0) {
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
@@ -96,7 +96,8 @@ __device__ __forceinline__ void ln_row_store(float (&v)[MAXV][4], int lane, int 
             if (y_f32) *reinterpret_cast<float4*>(y_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
             if (y_hi) {
                 uint2 h, l;
-                split4(y, h, l, f16);
+                if (dith && f16) split4_dither(y, h, l, dith);
+                else split4(y, h, l, f16);
                 *reinterpret_cast<uint2*>(y_hi + o) = h;
                 if (y_lo) *reinterpret_cast<uint2*>(y_lo + o) = l;
             }
@@ -287,7 +288,7 @@ __global__ void __launch_bounds__(256) step_embed_ln_kernel(didi_step_args a) {
         }
     }
     if (a.h_hi) ln_row_store<MAXV>(v, lane, H, row_off, a.ln_gamma, a.ln_beta, a.ln_eps, a.h_hi, a.h_lo, nullptr,
-                                  a.plane_format == DIDI_FMT_FP16);
+                                  a.plane_format == DIDI_FMT_FP16, a.act_dither);
 }
 
 extern "C" int didi_step_embed_ln(const didi_step_args* a, void* stream) {
@@ -297,6 +298,7 @@ extern "C" int didi_step_embed_ln(const didi_step_args* a, void* stream) {
     if (a->mode == DIDI_STEP_DDPM || a->mode == DIDI_STEP_EULER) DIDI_CHECK_ARG(a->X0);
     DIDI_CHECK_ARG(a->h_hi || a->x_out || a->xin_out);
     DIDI_CHECK_ARG(a->plane_format == DIDI_FMT_BF16 || a->plane_format == DIDI_FMT_FP16);
+    DIDI_CHECK_ARG(a->act_dither >= 0 && a->act_dither < 8192);
     if (a->h_hi) DIDI_CHECK_ARG(a->h_lo && a->time_embeds && a->pos_emb && a->tok_type0 && a->ln_gamma && a->ln_beta);
     if (a->H % 4 != 0 || a->H > 2048) return DIDI_ERR_UNSUPPORTED;
     if (a->M == 0) return DIDI_OK;

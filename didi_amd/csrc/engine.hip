@@ -77,9 +77,10 @@ bool small_enabled() { return didi_opt(DIDI_OPT_GEMM_SMALL) != 0; }
 
 int gemm(const didi_linear& w, int precision, int M, const u16* a_hi, const u16* a_lo, int lda, int act, const u16* r_hi,
          const u16* r_lo, int ldr, float* c_f32, u16* c_hi, u16* c_lo, int ldc, void* stream, Prof* prof = nullptr,
-         void* small_ws = nullptr, uint32_t* fault = nullptr) {
+         void* small_ws = nullptr, uint32_t* fault = nullptr, int dither = 0) {
     didi_gemm_args g{};
     g.fault = fault;
+    g.act_dither = precision == DIDI_PREC_FP16 ? dither : 0;
     g.M = M; g.N = w.N; g.K = w.K; g.precision = precision;
     g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
     g.W_hi = w.w_hi; g.W_lo = w.w_lo; g.ldw = w.K;
@@ -97,11 +98,12 @@ int gemm(const didi_linear& w, int precision, int M, const u16* a_hi, const u16*
 // else GEMM -> fp32 tmp -> LayerNorm.  `epoch` tags this launch's statistics in the shared `stats` buffer.
 int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi, const u16* a_lo, int lda, const u16* r_hi,
             const u16* r_lo, int ldr, float* tmp, void* stats, uint32_t epoch, const float* gamma, const float* beta, float eps,
-            u16* y_hi, u16* y_lo, float* y_f32, void* stream, Prof* prof, void* small_ws, uint32_t* fault) {
+            u16* y_hi, u16* y_lo, float* y_f32, void* stream, Prof* prof, void* small_ws, uint32_t* fault, int dither = 0) {
     const bool fuse = didi_opt(DIDI_OPT_GEMM_LN) != 0;  // 0: A/B switch back to GEMM + LayerNorm
     if (fuse && didi_gemm_ln_supported(M, w.N, w.K, precision) && w.bias) {
         didi_gemm_args g{};
         g.fault = fault;
+        g.act_dither = precision == DIDI_PREC_FP16 ? dither : 0;
         g.M = M; g.N = w.N; g.K = w.K; g.precision = precision;
         g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
         g.W_hi = w.w_hi; g.W_lo = w.w_lo; g.ldw = w.K;
@@ -220,6 +222,8 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
     const int x2_mask = didi_opt(DIDI_OPT_X2_GEMMS);
     auto pc = [&](int cls) { return prec == DIDI_PREC_FP16X2 && !((x2_mask >> cls) & 1) ? (int)DIDI_PREC_FP16 : prec; };
     const bool ffn_lo = x3;
+    DIDI_CHECK_ARG(a->act_dither >= 0 && a->act_dither < 8192);
+    const int dith = prec == DIDI_PREC_FP16 ? a->act_dither : 0;  // one-product calls only: the other precisions carry remainders
     const size_t Mc = (size_t)a->B * a->C;
     Prof prof{a->prof_events_host, a->prof_capacity, 0};
 
@@ -229,6 +233,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
     st.time_embeds = dec->time_embeds; st.pos_emb = dec->pos_emb; st.tok_type0 = dec->tok_type0;
     st.ln_gamma = dec->emb_ln_g; st.ln_beta = dec->emb_ln_b; st.ln_eps = dec->ln_eps;
     st.h_hi = w.h_hi; st.h_lo = w.h_lo; st.plane_format = fmt;
+    st.act_dither = dith;
     TRY(didi_step_embed_ln(&st, stream));
     // statistic granules of the fused projection+LayerNorm launches: cleared once, then one epoch per launch
     if (hipMemsetAsync(w.ln_stats, 0, w.ln_stats_bytes, as_stream(stream)) != hipSuccess) return DIDI_ERR_LAUNCH;
@@ -239,8 +244,9 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         const bool last = l == dec->L - 1;
         // --- causal self-attention block
         TRY(gemm(ly.qkv, pc(0), M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, w.qkv_hi,
-                 x3 ? w.qkv_lo : nullptr, 3 * H, stream, &prof, w.small_ws, a->fault));
+                 x3 ? w.qkv_lo : nullptr, 3 * H, stream, &prof, w.small_ws, a->fault, dith));
         didi_attn_args at{};
+        at.act_dither = dith;
         at.B = a->B; at.heads = dec->heads; at.Sq = a->S; at.Sk = a->S; at.D = D; at.precision = attn_prec;
         at.causal = 1; at.key_mask = nullptr;
         at.Q_hi = w.qkv_hi; at.Q_lo = x3 ? w.qkv_lo : nullptr; at.ldq = 3 * H;
@@ -249,11 +255,11 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.O_hi = w.att_hi; at.O_lo = x3 ? w.att_lo : nullptr; at.ldo = H;
         TRY(didi_attention(&at, stream));
         TRY(gemm_ln(ly.attn_out, pc(1), fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln1_g, ly.ln1_b,
-                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault));
+                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault, dith));
         // --- cross-attention block (K/V hoisted: didi_decoder_prepare_context)
         u16* q_hi = w.qkv_hi;
         u16* q_lo = x3 ? w.qkv_lo : nullptr;
-        TRY(gemm(ly.cq, pc(2), M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream, &prof, w.small_ws, a->fault));
+        TRY(gemm(ly.cq, pc(2), M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream, &prof, w.small_ws, a->fault, dith));
         const size_t kvoff = (size_t)l * Mc * 2 * H;
         at.Sk = a->C; at.causal = 0; at.key_mask = a->ctx_mask; at.key_count = a->ctx_count;
         at.Q_hi = q_hi; at.Q_lo = q_lo; at.ldq = H;
@@ -261,14 +267,14 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;
         TRY(didi_attention(&at, stream));
         TRY(gemm_ln(ly.cross_out, pc(3), fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln2_g, ly.ln2_b,
-                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault));
+                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault, dith));
         // --- feed-forward block
         TRY(gemm(ly.ffn_up, pc(4), M, w.h_hi, w.h_lo, H, DIDI_ACT_GELU, nullptr, nullptr, 0, nullptr, w.ffn_hi,
-                 ffn_lo ? w.ffn_lo : nullptr, I, stream, &prof, w.small_ws, a->fault));
+                 ffn_lo ? w.ffn_lo : nullptr, I, stream, &prof, w.small_ws, a->fault, dith));
         u16* o_hi = last && a->x0_hi ? a->x0_hi : w.h_hi;
         u16* o_lo = last && a->x0_hi ? a->x0_lo : w.h_lo;
         TRY(gemm_ln(ly.ffn_down, pc(5), fmt, M, w.ffn_hi, w.ffn_lo, I, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln3_g, ly.ln3_b,
-                    dec->ln_eps, o_hi, o_lo, last ? a->x0_f32 : nullptr, stream, &prof, w.small_ws, a->fault));
+                    dec->ln_eps, o_hi, o_lo, last ? a->x0_f32 : nullptr, stream, &prof, w.small_ws, a->fault, dith));
     }
     if (a->prof_used_host) *a->prof_used_host = prof.used;
     return DIDI_OK;
@@ -301,6 +307,8 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
     // precision schedule: one precision per denoiser call (all on the plane format of `precision`)
     auto prec_of = [&](int k) { return s->precision_host ? s->precision_host[k] : s->precision; };
     // one-product calls cycle through differently rounded copies of the weights (didi_sample_args.dec_variants_host)
+    // ... and round their fp16 activation planes with an offset that cycles too (didi_sample_args.act_dither)
+    auto dith_of = [&](int k) { return s->act_dither && prec_of(k) == DIDI_PREC_FP16 ? 1024 + 2048 * ((k + k / 4) & 3) : 0; };
     auto dec_of = [&](int k) { return s->dec_variants_host && s->n_variants > 0 && prec_of(k) == DIDI_PREC_FP16 ? s->dec_variants_host[k % s->n_variants] : dec; };
     // per-step clamp extension: x0 <- emb[argmax(classifier(x0))]; the forward leaves x0 planes for the rounding GEMM
     const bool clamp = s->clamp_emb != nullptr;
@@ -339,6 +347,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
             st.xin_out = s->xt_trace ? s->xt_trace + (size_t)k * MH : nullptr;
             set_prof(k);
             f.precision = prec_of(k);
+            f.act_dither = dith_of(k);
             const bool last = k == s->n_calls - 1;
             f.x0_hi = last || clamp ? s->x0_hi : nullptr;
             f.x0_lo = last || clamp ? s->x0_lo : nullptr;
@@ -372,6 +381,7 @@ extern "C" int didi_sample(const didi_decoder* dec, const didi_sample_args* s, v
             f.x0_hi = clamp ? s->x0_hi : nullptr;
             f.x0_lo = clamp ? s->x0_lo : nullptr;
             f.precision = prec_of(k);
+            f.act_dither = dith_of(k);
             set_prof(k);
             TRY(didi_decoder_forward(dec_of(k), &f, stream));
             if (clamp) TRY(clamp_x0());

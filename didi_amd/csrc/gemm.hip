@@ -73,6 +73,8 @@ struct GemmParams {
     unsigned long long* ln_stats;  // [tiles_m][tiles_n][256][2] granules {epoch, bits} of each tile's per-row (sum, M2)
     unsigned ln_epoch;             // tag of this launch's granules (>= 1; older tags and zero are stale)
     uint32_t* fault;               // device fault word (DIDI_FAULT_*) or null
+    int dither;                    // fp16 activation-plane rounding dither of this launch (common.hpp f16x2_dither), 0 = RNE;
+                                   // honoured by the one-product fp16 form of gemm_pp_kernel (the sampler's hot path)
 };
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
@@ -370,7 +372,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
 // a dependent global load at the head of the epilogue cost the qkv launch 5 us per round, tools/epi_cost.py)
 __device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32x4 lo4, f32x4 hi4, const float2* gelu_tbl, float& amax,
                                           int pre = 0, uint4 rh_pre = uint4{0, 0, 0, 0}, uint4 rl_pre = uint4{0, 0, 0, 0},
-                                          const float* bias8 = nullptr) {
+                                          const float* bias8 = nullptr, int dith = 0) {
     float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     if (p.bias) {
         const float* bsrc = bias8 ? bias8 : p.bias + n;
@@ -414,12 +416,12 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, int m, int n, f32
     amax = amax2(amax2(amax2(amax2(amax, v[0], v[1]), v[2], v[3]), v[4], v[5]), v[6], v[7]);
     if (p.C_hi && p.C_lo) {
         uint2 h0, l0, h1, l1;
-        split4(v, h0, l0, p.f16);
-        split4(v + 4, h1, l1, p.f16);
+        if (dith) { split4_dither(v, h0, l0, dith); split4_dither(v + 4, h1, l1, dith); }
+        else { split4(v, h0, l0, p.f16); split4(v + 4, h1, l1, p.f16); }
         *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
         *reinterpret_cast<uint4*>(p.C_lo + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     } else if (p.C_hi) {  // one-product precisions keep no remainder of GEMM-only operands
-        const uint2 h0 = pack4_hi(v, p.f16), h1 = pack4_hi(v + 4, p.f16);
+        const uint2 h0 = dith ? pack4_hi_dither(v, dith) : pack4_hi(v, p.f16), h1 = dith ? pack4_hi_dither(v + 4, dith) : pack4_hi(v + 4, p.f16);
         *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
     }
 }
@@ -848,6 +850,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     // residual planes: all 12 loads of half a wave tile are issued before the first use (the fragment
     // registers are dead by now), instead of one exposed memory round trip per 8 columns
     const int pre = p.R_hi != nullptr && p.R_f32 == nullptr;
+    const int dith = NPASS == 1 && F16 ? p.dither : 0;  // activation-plane rounding dither: one-product fp16 launches only
     if constexpr (F16) f16_saturate_mode();
     if constexpr (!LN) {
         float amax = 0.f;
@@ -875,7 +878,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const int n = n0 + wn * 96 + 32 * k + 8 * lg;
-                    if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi], gelu_tbl, amax, pre, rh[mj][k], rl[mj][k], bias_lds + (n - n0));
+                    if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi], gelu_tbl, amax, pre, rh[mj][k], rl[mj][k], bias_lds + (n - n0), dith);
                     else if (n < p.N) epilogue4(p, m, n, acc[2 * k][mi][0], acc[2 * k][mi][1], acc[2 * k][mi][2], acc[2 * k][mi][3], amax);
                 }
             }
@@ -1032,8 +1035,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                     *reinterpret_cast<float4*>(p.C_f32 + o + 4) = make_float4(y[4], y[5], y[6], y[7]);
                 }
                 uint2 h0, l0, h1, l1;
-                split4(y, h0, l0, p.f16);
-                split4(y + 4, h1, l1, p.f16);
+                if (dith) { split4_dither(y, h0, l0, dith); split4_dither(y + 4, h1, l1, dith); }
+                else { split4(y, h0, l0, p.f16); split4(y + 4, h1, l1, p.f16); }
                 *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
                 *reinterpret_cast<uint4*>(p.C_lo + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
             }
@@ -1152,6 +1155,8 @@ extern "C" int didi_gemm(const didi_gemm_args* a, void* stream) {
     p.R_f32 = a->R_f32; p.R_hi = a->R_hi; p.R_lo = a->R_lo; p.ldr = a->ldr;
     p.C_f32 = a->C_f32; p.C_hi = a->C_hi; p.C_lo = a->C_lo; p.ldc = a->ldc;
     p.fault = a->fault;
+    DIDI_CHECK_ARG(a->act_dither >= 0 && a->act_dither < 8192);
+    p.dither = a->act_dither;
     hipStream_t st = as_stream(stream);
     const int mode = pick_mode(p);
     const int big_tiles_n = cdiv(a->N, BBN);
@@ -1408,6 +1413,8 @@ extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const f
     if (rc != DIDI_OK) return rc;
     p.lda = a->lda; p.ldw = a->ldw; p.bias = a->bias; p.act = DIDI_ACT_NONE; p.ldr = a->ldr; p.ldc = a->N;
     p.ln_gamma = gamma; p.ln_beta = beta; p.ln_eps = eps; p.tiles_n = 4; p.fault = a->fault;
+    DIDI_CHECK_ARG(a->act_dither >= 0 && a->act_dither < 8192);
+    p.dither = a->act_dither;
     hipStream_t st = as_stream(stream);
     const int bands = cdiv(a->M, 256);
     if (epoch == 0) {  // stand-alone use: clear the granules, then tag 1

@@ -87,7 +87,7 @@ class _Classifier:
 
 class DiDiSampler:
     def __init__(self, state_dict, cfg: DiDiConfig, device="cuda", precision="bf16x3", schedule=None, tail_calls=None, weight_dither=None,
-                 encoder_only=False):
+                 encoder_only=False, act_dither=None):
         """``precision``: bf16 | fp16 (one MFMA product), fp16x2 (weights with their remainder), bf16x3 (fp32-class), or
         "fp16-sched": fp16 planes with the default precision schedule ``DEFAULT_SCHEDULE``.
         ``schedule``: precision schedule of ``sample`` over the TIMESTEP of each denoiser call, a tuple of (t_above, precision)
@@ -98,6 +98,8 @@ class DiDiSampler:
         ``weight_dither``: P > 1 keeps P differently rounded fp16 copies of the per-call GEMM weights and cycles the one-product
         calls of a loop through them (``_build_weight_variants``); fp16 planes only ("fp16-sched" defaults to
         ``DEFAULT_WEIGHT_DITHER``, everything else to none).
+        ``act_dither``: the one-product calls of a loop round their fp16 ACTIVATION planes with an offset that cycles over
+        four values (didi_sample_args.act_dither: the activation-side twin of ``weight_dither``); fp16 planes only.
         ``encoder_only``: build the context encoder (+ adapter) and the schedule buffers only -- what the trainer's frozen part
         needs (didi_amd/trainer.py); the decoder, embedding and classifier planes are not allocated and sampling is refused."""
         schedule_euler = None
@@ -130,6 +132,7 @@ class DiDiSampler:
             schedule_euler = resolve(schedule_euler)
         self.cfg, self.device, self.precision = cfg, torch.device(device), precision
         self.weight_dither = int(weight_dither or 0) if precision in ("fp16", "fp16x2") else 0
+        self.act_dither = bool(act_dither) and precision in ("fp16", "fp16x2")
         self.schedule = schedule
         self.schedule_euler = schedule_euler if schedule_euler is not None else schedule  # "fp16-sched": DEFAULT_SCHEDULE_EULER
         self.tail_calls = tuple(tail_calls or ())  # an explicit schedule is taken as written unless floors are given too
@@ -239,6 +242,10 @@ class DiDiSampler:
             d.layers_host = C.cast(layers, C.POINTER(_lib.DecoderLayer))
             self._dec_variants.append((d, layers))
         self._dec_variant_ptrs = (C.c_void_p * P)(*[C.addressof(d) for d, _ in self._dec_variants])
+
+    def act_dither_for_call(self, k, prec):
+        """didi_forward_args.act_dither of call k of a loop (Python-loop twin of the engine's rule, engine.hip dith_of)."""
+        return 1024 + 2048 * ((k + k // 4) & 3) if self.act_dither and prec == _lib.PREC_FP16 else 0
 
     def dec_for_call(self, k, prec):
         """The decoder description call k of a loop runs with (Python-loop twin of the engine's choice)."""

@@ -140,6 +140,7 @@ def sample(raw_context, model, mode, step_freq, noise_factor=1, tokenizer=None, 
         precs = model.call_precisions(plan.time_row, mode)
         prec_arr = (C.c_int * n_calls)(*precs) if precs is not None else None  # kept alive until the call returns
         a.precision_host = prec_arr if prec_arr is not None else C.cast(None, C.POINTER(C.c_int))
+        a.act_dither = int(model.act_dither)
         if model._dec_variants:  # one-product calls cycle through differently rounded weight planes (DiDiSampler(weight_dither=P))
             a.dec_variants_host, a.n_variants = model._dec_variant_ptrs, len(model._dec_variants)
         if _prof is not None:  # bench.py: HIP events around the GEMM launches of chosen denoiser calls
@@ -197,6 +198,7 @@ def _loop_torch_noise(model, plan, mode, b, B, S, Cn, trace, clamp=False):
         fa.workspace, fa.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
         fa.x0_f32 = x0.data_ptr()
         fa.fault = b["fault"].data_ptr()
+        fa.act_dither = model.act_dither_for_call(k, fa.precision)
         _lib.check(lib.didi_decoder_forward(C.byref(model.dec_for_call(k, fa.precision)), C.byref(fa), _lib.current_stream()), "decoder_forward")
         if clamp:
             clamp_x0()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DIDI_ABI_VERSION 4
+#define DIDI_ABI_VERSION 5
 
 enum {
     DIDI_OK = 0,
@@ -154,6 +154,7 @@ typedef struct didi_step_args {
     uint16_t* h_hi; /* [M,H] or NULL to skip the embedding/LayerNorm part */
     uint16_t* h_lo; /* [M,H] */
     int plane_format; /* DIDI_FMT_* of h_hi / h_lo */
+    int act_dither;   /* fp16 planes: rounding dither of h_hi (see didi_gemm_args.act_dither); 0 = round to nearest */
 } didi_step_args;
 int didi_step_embed_ln(const didi_step_args* a, void* stream);
 
@@ -208,6 +209,14 @@ typedef struct didi_gemm_args {
     uint16_t *C_hi, *C_lo; /* or NULL */
     int ldc;
     uint32_t* fault;       /* device fault word (DIDI_FAULT_*) or NULL */
+    /* Rounding dither of the fp16 hi plane this launch writes (no reference counterpart: the reference keeps fp32).  0 = round
+     * to nearest even.  d in 1..8191 = truncate after adding d / 8192 of an fp16 ulp to the magnitude; a sampling loop passes
+     * 1024, 3072, 5120, 7168 in turn to its one-product calls, so that the mean of four consecutive roundings of a static
+     * activation is within ulp / 8 of it instead of every call rounding it the same way (errors that are the same at every
+     * call add up coherently over the loop).  The remainder plane stays C_lo = rne16(v - C_hi).
+     * Honoured by DIDI_PREC_FP16 launches on the 256x192 tile (M >= 2048: the sampler's hot path) and didi_gemm_ln;
+     * ignored (plain rounding) by every other form. */
+    int act_dither;
 } didi_gemm_args;
 int didi_gemm(const didi_gemm_args* a, void* stream);
 
@@ -261,9 +270,11 @@ int didi_round_argmax(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const
  * Same arithmetic, same kernels, same results as didi_round_argmax; the (max, index) partials live in a file-scope device
  * array of didi_round_argmax_static_max_bytes() = 16 MiB that every GPU the library runs on holds until the process ends.
  * Shapes with didi_round_argmax_bytes(M, V) = M * ceil(V / 128) * 8 above that limit are rejected with DIDI_ERR_WORKSPACE
- * (it covers M = 16384 at V = 8008 and M = 5376 at V = 50000).  Allocates nothing, frees nothing, synchronises nothing.
- * Calls that overlap on one GPU (two streams, two threads) share the array and race: serialise them.  The first call on a
- * device resolves the array's device address (hipGetSymbolAddress): make it outside graph capture. */
+ * (the largest M is floor(2097152 / ceil(V / 128)): M = 16384 fits at V = 8008, M = 5363 at V = 50000).  Allocates nothing,
+ * frees nothing, synchronises nothing.  Calls that overlap on one GPU (two streams, two threads) share the array and race:
+ * serialise them.  The first call on a device does per-device set-up that must not happen under graph capture: here the
+ * array's device address (hipGetSymbolAddress), in the GEMM the device-attribute query and the kernels' LDS opt-ins
+ * (hipFuncSetAttribute).  A caller that captures makes one warm-up call of the same shape on each device first. */
 size_t didi_round_argmax_static_max_bytes(void);
 int didi_round_argmax_static(const uint16_t* X_hi, const uint16_t* X_lo, int ldx, const uint16_t* W_hi, const uint16_t* W_lo,
                              int ldw, int M, int V, int K, int precision, int64_t* ids64, int32_t* ids32, void* stream);
@@ -324,6 +335,8 @@ typedef struct didi_attn_args {
                               first key_count[b] keys (right padding, commonsense_dataset.py:27-32).  The kernel then neither
                               loads nor multiplies the padded keys (their softmax weight is exactly 0): same result, less
                               traffic.  NULL, or a count of 0 or Sk: the full masked path. */
+    int act_dither;        /* DIDI_PREC_FP16 / FP16X2: rounding dither (didi_gemm_args.act_dither) of the probabilities' and the
+                              output's fp16 planes; 0 = round to nearest */
 } didi_attn_args;
 int didi_attention(const didi_attn_args* a, void* stream);
 /* counts[b] = number of visible keys of mask[b, :] (int32 [B, Sk]) if they form a prefix, else Sk (no trimming). */
@@ -406,6 +419,8 @@ typedef struct didi_forward_args {
     int prof_capacity;
     int* prof_used_host;
     uint32_t* fault; /* device fault word (DIDI_FAULT_*) or NULL */
+    int act_dither;  /* DIDI_PREC_FP16 calls: rounding dither of every fp16 activation plane this call writes (embeddings
+                        LayerNorm, GEMM epilogues, attention probabilities and outputs): didi_gemm_args.act_dither.  0 = none */
 } didi_forward_args;
 int didi_decoder_forward(const didi_decoder* dec, const didi_forward_args* a, void* stream);
 
@@ -473,6 +488,11 @@ typedef struct didi_sample_args {
      * up coherently over the loop) but averages out over n_variants consecutive calls.  Calls of the other precisions use `dec`. */
     const didi_decoder* const* dec_variants_host;
     int n_variants;
+    /* activation dither for the ONE-PRODUCT (FP16) calls of the loop: != 0 -> call k of precision FP16 rounds its fp16
+     * activation planes with didi_forward_args.act_dither = 1024 + 2048 * ((k + k / 4) % 4) (the phase advances by one
+     * every four calls relative to the weight variant k % n_variants, so that over 16 calls every weight variant meets every
+     * activation offset once).  Calls of the other precisions round to nearest. */
+    int act_dither;
 } didi_sample_args;
 int didi_sample(const didi_decoder* dec, const didi_sample_args* a, void* stream);
 

@@ -226,8 +226,13 @@ def test_config2_shape_euler_f10_full_loop_and_batch_invariance():
 
 
 def test_config3_shape_large_vocab_clamp():
-    """BASELINE configs[3]: V = 50 000, S = C = 84, B = 1024 (M = 86 016 rows), per-step clamp ON, two denoiser calls
-    (T = 2): rounding GEMM 6.6 TFLOP per call with the logits (17 GB) never written.  The oracle runs the first 2 dialogs."""
+    """BASELINE configs[3] at length: V = 50 000, S = C = 84, B = 1024 (M = 86 016 rows), per-step clamp ON, T = 2000 with
+    step_freq = 50: 41 denoiser calls, each followed by the rounding GEMM (6.6 TFLOP, the 17 GB of logits never written), the
+    embedding gather and the sampler update.  The CPU oracle runs the first 2 dialogs (168 positions) with the same injected
+    noise.  With the clamp every x0 is an exact embedding row, so a denoiser input x_t either agrees with the oracle's to
+    rounding (same clamped id at the previous call) or is another token's embedding: the bars are, at EVERY call, >= 99 % of
+    the rows within 1e-4 rel-L2 of the oracle's row, and final ids >= 99 %.  (An extension: the reference never clamps --
+    parity unpinned by the reference, pinned on the oracle's restatement of the rule.)"""
     from didi_amd.config import DiDiConfig
     from didi_amd.model import DiDiSampler
     from didi_amd.sampling import sample
@@ -235,29 +240,46 @@ def test_config3_shape_large_vocab_clamp():
     from oracle.model import OracleDiDi
     from oracle.sampling import Context, sample as oracle_sample
 
-    cfg = DiDiConfig(vocab=50000, diffusion_steps=2)
+    cfg = DiDiConfig(vocab=50000, diffusion_steps=2000)
     sd = synthetic_state_dict(cfg, seed=4321)
-    B, Bo, C, S = 1024, 2, 84, 84
+    B, Bo, C, S, f = 1024, 2, 84, 84, 50
     ids, mask = synthetic_batch(B, C, cfg.vocab, seed=17)
+    n_calls = len(range(cfg.diffusion_steps, 1, -f)) + 1
+    assert n_calls == 41
     g = torch.Generator().manual_seed(33)
-    noise = torch.randn(2, B, S, cfg.dec_dim, generator=g)
+    small = torch.randn(n_calls, Bo, S, cfg.dec_dim, generator=g)  # the oracle's dialogs; the other 1022 draw on the device
+    noise = torch.empty(n_calls, B, S, cfg.dec_dim, device="cuda")
+    gd = torch.Generator(device="cuda").manual_seed(34)
+    for i in range(n_calls):
+        noise[i].normal_(generator=gd)
+    noise[:, :Bo] = small.cuda()
     want_trace = []
-    want = oracle_sample(Context(ids[:Bo], mask[:Bo]), OracleDiDi(sd, config_to_oracle_config(cfg)), "ddpm", 1, max_len=S,
-                         raw_output=True, noise_source=ListNoise([noise[0, :Bo], noise[1, :Bo]]), trace=want_trace, clamp=True)
-    model = DiDiSampler(sd, cfg, device="cuda", precision="fp16-sched")
-    trace = []
-    got, lengths = sample(_ctx(ids, mask), model, "ddpm", 1, max_len=S, noise=noise.cuda(), return_ids=True, trace=trace, clamp=True)
-    model.check_fault("config3 shape")
-    assert tuple(got.shape) == (B, S) and int(got.min()) >= 0 and int(got.max()) < cfg.vocab
-    match = (got[:Bo].cpu() == want.argmax(-1)).float().mean().item()
-    # call 1's input depends on call 0's clamped ids: a differing id there moves x_t, so report both and bound the first call
-    e0 = rel_l2(trace[0][:Bo], want_trace[0])
-    e1 = rel_l2(trace[1][:Bo], want_trace[1])
-    print(f"\n[config3 shape fp16-sched, clamp] id match {match:.4f} on {Bo * S} positions; x_t rel-L2 call 0 {e0:.3e}, call 1 {e1:.3e}")
-    assert e0 <= 1e-6  # the initial noise, scaled
-    assert match >= 0.97  # random-init weights at V = 50 000: top-2 gaps are small, a clamp flip feeds back (parity unpinned by the reference)
-    top_share = got.flatten().bincount(minlength=cfg.vocab).max().item() / got.numel()
-    assert top_share < 0.05
+    t0 = time.time()
+    want = oracle_sample(Context(ids[:Bo], mask[:Bo]), OracleDiDi(sd, config_to_oracle_config(cfg)), "ddpm", f, max_len=S,
+                         raw_output=True, noise_source=TickNoise([small[i] for i in range(n_calls)]), trace=want_trace, clamp=True)
+    print(f"\n[config3 shape] oracle: {n_calls} calls x {Bo} dialogs, V = {cfg.vocab}, in {time.time() - t0:.0f} s")
+    for precision in ("fp16-sched", "bf16x3"):
+        model = DiDiSampler(sd, cfg, device="cuda", precision=precision)
+        trace = []
+        t0 = time.time()
+        got, lengths = sample(_ctx(ids, mask), model, "ddpm", f, max_len=S, noise=noise, return_ids=True, trace=trace, clamp=True)
+        model.check_fault("config3 shape")
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        assert tuple(got.shape) == (B, S) and int(got.min()) >= 0 and int(got.max()) < cfg.vocab and len(trace) == n_calls
+        match = (got[:Bo].cpu() == want.argmax(-1)).float().mean().item()
+        share = []
+        for a, b in zip(trace, want_trace):
+            a, b = a[:Bo].cpu().double().view(Bo * S, -1), b.double().view(Bo * S, -1)
+            share.append(float((((a - b).norm(dim=1) / b.norm(dim=1)) <= 1e-4).float().mean()))
+        print(f"[config3 shape {precision}, clamp, {n_calls} calls x {B} dialogs in {dt:.1f} s] final id match {match:.4f} on {Bo * S} positions; "
+              f"share of rows within 1e-4 of the oracle's x_t: min {min(share):.4f} (call {share.index(min(share))}), last {share[-1]:.4f}")
+        assert share[0] == 1.0  # the initial noise, scaled
+        assert min(share) >= 0.99 and match >= 0.99
+        top_share = got.flatten().bincount(minlength=cfg.vocab).max().item() / got.numel()
+        assert top_share < 0.05
+        del model, trace
+        torch.cuda.empty_cache()
 
 
 def test_id_agreement_config1_2208_positions():

@@ -424,11 +424,13 @@ def test_overlapped_reducer_covers_every_gradient_once(precision):
 
 
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
-def test_save_and_resume_is_bit_identical_to_an_uninterrupted_run(tmp_path, dropout):
+def test_save_and_resume_continues_an_uninterrupted_run(tmp_path, dropout):
     """Checkpoint / resume (src/training.py:27-33,47: ModelCheckpoint every save_interval steps, trainer.fit(ckpt_path=resume)):
     three steps, save, then a FRESH trainer built from the original weights loads the file and takes step four -- parameters,
-    both AdamW moments, the step count (LR lambda, bias correction) and the step's loss must equal, bit for bit, those of a
-    trainer that took the four steps without interruption.  The file is plain tensors: torch.load(weights_only=True) reads it,
+    both AdamW moments, the step count (LR lambda, bias correction) and the step's loss must equal those of a trainer that took
+    the four steps without interruption, to the run-to-run noise of the backward's fp32 atomic adds (embedding gradients:
+    two identical runs differ in the last bits; bar 1e-6 relative, a resume WITHOUT the optimiser state is 1e-3 away).  The
+    file is plain tensors: torch.load(weights_only=True) reads it,
     and it loads into a DiDiSampler like a reference checkpoint."""
     from didi_amd.checkpoint import load_lightning_checkpoint
 
@@ -452,8 +454,10 @@ def test_save_and_resume_is_bit_identical_to_an_uninterrupted_run(tmp_path, drop
     c.load_checkpoint(path)
     assert c.step_count == 3
     oa, oc = step(a, 3), step(c, 3)
-    assert torch.equal(oa["metrics"], oc["metrics"]) and torch.equal(oa["grad_norm"], oc["grad_norm"])
-    assert torch.equal(a._flat_p, c._flat_p) and torch.equal(a._flat_m, c._flat_m) and torch.equal(a._flat_v, c._flat_v)
+    assert torch.allclose(oa["metrics"], oc["metrics"], rtol=1e-5, atol=0) and torch.allclose(oa["grad_norm"], oc["grad_norm"], rtol=1e-5)
+    e_p, e_m, e_v = rel_l2(c._flat_p, a._flat_p), rel_l2(c._flat_m, a._flat_m), rel_l2(c._flat_v, a._flat_v)
+    print(f"\n[resume, dropout {dropout}] after step 4, resumed vs uninterrupted: parameters {e_p:.1e}, exp_avg {e_m:.1e}, exp_avg_sq {e_v:.1e}")
+    assert e_p <= 1e-6 and e_m <= 1e-5 and e_v <= 1e-5
     assert a.step_count == c.step_count == 4
     # without the optimiser state the run does NOT continue: same weights, zero moments, step 0 -> another step four
     _, _, _, d, _, _ = _trainer("train_tiny_plain", **kw)
@@ -461,7 +465,7 @@ def test_save_and_resume_is_bit_identical_to_an_uninterrupted_run(tmp_path, drop
         p_.copy_(ck["state_dict"][k_])
     d.refresh_planes()
     step(d, 3)
-    assert not torch.equal(a._flat_p, d._flat_p)
+    assert rel_l2(d._flat_p, a._flat_p) > 100 * max(e_p, 1e-8)
     # mismatched optimiser settings are refused; the file is also a sampler checkpoint in the reference's key layout
     _, _, _, e, _, _ = _trainer("train_tiny_plain", opt_kwargs=dict(optk, lr=1e-3))
     with pytest.raises(ValueError):

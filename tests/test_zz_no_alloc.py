@@ -61,5 +61,6 @@ def test_round_argmax_static_rejects_what_does_not_fit():
     w_hi = torch.zeros((V, K), dtype=torch.float16, device="cuda")
     rc, _ = _static((x_hi, x_hi), (w_hi, w_hi), "fp16")
     assert rc == -4 and b"workspace" in _lib.lib.didi_error_string(rc)
-    # the largest bench shape fits
+    # the largest bench shape fits; at V = 50000 (391 chunks of 128) the boundary is M = floor(2097152 / 391) = 5363
     assert _lib.lib.didi_round_argmax_bytes(16384, 8008) <= limit
+    assert _lib.lib.didi_round_argmax_bytes(5363, 50000) <= limit < _lib.lib.didi_round_argmax_bytes(5364, 50000)

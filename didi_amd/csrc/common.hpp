@@ -70,13 +70,16 @@ __device__ __forceinline__ uint32_t f16x2_dither(float a, float b, int d) {
 __device__ __forceinline__ uint2 pack4_hi_dither(const float v[4], int d) {
     return make_uint2(f16x2_dither(v[0], v[1], d), f16x2_dither(v[2], v[3], d));
 }
+// DIDI_RNE_AS_DITHER: the offset that makes the truncating conversion round to nearest (ties away from zero instead of to even:
+// one value in 2^13 differs from RNE, by an ulp's rounding direction).  The 256x192 GEMM's fp16 epilogues convert through
+// f16x2_dither always -- 1.5 VALU instructions per value against 2.5 for two v_cvt_f16_f32 and a v_perm_b32.
+#define DIDI_RNE_AS_DITHER 4096
 __device__ __forceinline__ void split4_dither(const float v[4], uint2& hi, uint2& lo, int d) {
     hi = pack4_hi_dither(v, d);
-    const u16 h[4] = {(u16)(hi.x & 0xffff), (u16)(hi.x >> 16), (u16)(hi.y & 0xffff), (u16)(hi.y >> 16)};
-    u16 l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) l[i] = f16_bits(v[i] - f16_to_f32(h[i]));
-    lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = __builtin_bit_cast(h2, hi.x), b = __builtin_bit_cast(h2, hi.y);
+    const float r[4] = {v[0] - (float)a[0], v[1] - (float)a[1], v[2] - (float)b[0], v[3] - (float)b[1]};
+    lo = pack4_hi_dither(r, DIDI_RNE_AS_DITHER);
 }
 
 // 4 consecutive values -> two 8-byte packs (hi plane, lo plane)

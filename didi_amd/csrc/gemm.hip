@@ -36,6 +36,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -73,9 +74,30 @@ struct GemmParams {
     unsigned long long* ln_stats;  // [tiles_m][tiles_n][256][2] granules {epoch, bits} of each tile's per-row (sum, M2)
     unsigned ln_epoch;             // tag of this launch's granules (>= 1; older tags and zero are stale)
     uint32_t* fault;               // device fault word (DIDI_FAULT_*) or null
+    unsigned long long* stamps;    // diagnostic builds (-DDIDI_STAMPS) only: s_memtime stamps [workgroup][wave group][16]
     int dither;                    // fp16 activation-plane rounding dither of this launch (common.hpp f16x2_dither), 0 = RNE;
                                    // honoured by the one-product fp16 form of gemm_pp_kernel (the sampler's hot path)
 };
+
+// In-kernel stamps of gemm_pp_kernel (diagnostic build only: in the product library PP_STAMP expands to nothing).  Lane 0 of
+// waves 0 (early wave group) and 4 (late group) writes s_memtime at fixed points of the kernel into p.stamps, a buffer of
+// its own that nothing else reads (MI355X_MICROARCH.md, DVFS give-back item 6); slots 14 / 15 hold s_memrealtime (100 MHz) at
+// the first and last stamp so the in-kernel clock can be derived.  tools/ln_stamps.py reads them.
+#ifdef DIDI_STAMPS
+static unsigned long long* g_stamp_buf = nullptr;
+extern "C" void didi_debug_set_stamps(void* buf) { g_stamp_buf = reinterpret_cast<unsigned long long*>(buf); }
+#define PP_STAMP(i)                                                                                          \
+    do {                                                                                                     \
+        if (p.stamps && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) & 3) == 0) {                          \
+            unsigned long long* s_ = p.stamps + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 8)) * 16;          \
+            s_[i] = __builtin_amdgcn_s_memtime();                                                            \
+            if ((i) == 0) s_[14] = __builtin_amdgcn_s_memrealtime();                                         \
+            if ((i) == 7) s_[15] = __builtin_amdgcn_s_memrealtime();                                         \
+        }                                                                                                    \
+    } while (0)
+#else
+#define PP_STAMP(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 __device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4); }
@@ -741,6 +763,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         if (wave == 1 && lane < 48) glds16(reinterpret_cast<const u16*>(p.ln_gamma + n0 + 4 * lane), reinterpret_cast<char*>(gamma_lds));
         if (wave == 2 && lane < 48) glds16(reinterpret_cast<const u16*>(p.ln_beta + n0 + 4 * lane), reinterpret_cast<char*>(beta_lds));
     }
+    PP_STAMP(0);
     // tile 0 must have landed before the first read; tile 1 stays in flight (first waits: end of B2_0)
     if (grp == 0) {
         PP_ISSUE(0, 0, 6);
@@ -754,6 +777,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    PP_STAMP(1);  // first K-tile landed: the loop starts
     if (grp == 0) {
         for (int i = 0; i < nt; ++i) {
             const char* st = smem + (i & 1) * STAGE;
@@ -799,6 +823,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #undef PP_ISSUE
 #undef PP_READ
 #undef PP_MFMA
+    PP_STAMP(2);  // K-loop done (this wave group)
     if constexpr (AMAX) {
         // lane (lr, lg) of wave (wm, wn) holds, for row wm*64 + mi*16 + lr, the columns wn*96 + 32k + 8lg + 4h + r of tile ni = 2k + h
         float best[4];
@@ -852,6 +877,59 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     const int pre = p.R_hi != nullptr && p.R_f32 == nullptr;
     const int dith = NPASS == 1 && F16 ? p.dither : 0;  // activation-plane rounding dither: one-product fp16 launches only
     if constexpr (F16) f16_saturate_mode();
+    if constexpr (!LN && F16) {
+        // Straight-line epilogue for the sampler's own launches (qkv, cross-attention query, FFN up): full tile, bias from LDS,
+        // no residual, planes out only.  The general epilogue8 below decides all of that per 8 values with scalar branches and
+        // converts every value to BOTH plane formats behind a select (p.f16 is a run-time field there): stamps put it at
+        // 7.4 us per tile against 11 us for the whole 12-tile K-loop (profiles/r03_ln_stamps.log).  Here the format is the
+        // template's, the conversions are packed (f16x2_dither: 1.5 VALU per value) and nothing branches inside the loops.
+        const bool fast = p.bias && !p.R_f32 && !p.R_hi && !p.C_f32 && p.C_hi && m0 + 256 <= p.M && n0 + BBN <= p.N &&
+                          (p.act == DIDI_ACT_NONE || use_lut);
+        if (fast) {
+            const int d = dith ? dith : DIDI_RNE_AS_DITHER;
+            float amax = 0.f;
+            auto run = [&](auto gelu_c, auto lo_c) {
+                constexpr bool GELU = decltype(gelu_c)::value, LO = decltype(lo_c)::value;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const size_t row = (size_t)(m0 + wm * 64 + mi * 16 + lr) * p.ldc + n0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int nl = wn * 96 + 32 * k + 8 * lg;
+                        const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + nl), b1 = *reinterpret_cast<const float4*>(bias_lds + nl + 4);
+                        float v[8] = {acc[2 * k][mi][0] + b0.x, acc[2 * k][mi][1] + b0.y, acc[2 * k][mi][2] + b0.z, acc[2 * k][mi][3] + b0.w,
+                                      acc[2 * k + 1][mi][0] + b1.x, acc[2 * k + 1][mi][1] + b1.y, acc[2 * k + 1][mi][2] + b1.z, acc[2 * k + 1][mi][3] + b1.w};
+                        if constexpr (GELU) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] = gelu_lut(v[i], gelu_tbl);
+                        }
+                        amax = amax2(amax2(amax2(amax2(amax, v[0], v[1]), v[2], v[3]), v[4], v[5]), v[6], v[7]);
+                        if constexpr (LO) {
+                            uint2 h0, l0, h1, l1;
+                            split4_dither(v, h0, l0, d);
+                            split4_dither(v + 4, h1, l1, d);
+                            *reinterpret_cast<uint4*>(p.C_hi + row + nl) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                            *reinterpret_cast<uint4*>(p.C_lo + row + nl) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                        } else {
+                            const uint2 h0 = pack4_hi_dither(v, d), h1 = pack4_hi_dither(v + 4, d);
+                            *reinterpret_cast<uint4*>(p.C_hi + row + nl) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                        }
+                    }
+                }
+            };
+            using T_ = std::true_type;
+            using F_ = std::false_type;
+            if (use_lut) { if (p.C_lo) run(T_{}, T_{}); else run(T_{}, F_{}); }
+            else { if (p.C_lo) run(F_{}, T_{}); else run(F_{}, F_{}); }
+            PP_STAMP(6);
+#ifdef DIDI_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            PP_STAMP(7);
+            raise_fault(p.fault, amax > DIDI_F16_MAX, DIDI_FAULT_FP16_RANGE);
+            return;
+        }
+    }
     if constexpr (!LN) {
         float amax = 0.f;
 #pragma unroll
@@ -883,6 +961,11 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                 }
             }
         }
+        PP_STAMP(6);  // every store issued
+#ifdef DIDI_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        PP_STAMP(7);  // ... and drained
         if constexpr (F16) raise_fault(p.fault, p.C_hi != nullptr && amax > DIDI_F16_MAX, DIDI_FAULT_FP16_RANGE);
     } else {
         // ---- fused LayerNorm: the tiles_n (= 4) workgroups of a 256-row band each hold 192 of the 768 columns
@@ -915,10 +998,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                     const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + (n - n0)), b1 = *reinterpret_cast<const float4*>(bias_lds + (n - n0) + 4);
                     const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
                     float rH[8], rL[8];
-                    unpack4(make_uint2(rh[mj][k].x, rh[mj][k].y), rH, p.f16);
-                    unpack4(make_uint2(rh[mj][k].z, rh[mj][k].w), rH + 4, p.f16);
-                    unpack4(make_uint2(rl[mj][k].x, rl[mj][k].y), rL, p.f16);
-                    unpack4(make_uint2(rl[mj][k].z, rl[mj][k].w), rL + 4, p.f16);
+                    unpack4(make_uint2(rh[mj][k].x, rh[mj][k].y), rH, F16);  // the template's format: p.f16 would convert both ways
+                    unpack4(make_uint2(rh[mj][k].z, rh[mj][k].w), rH + 4, F16);
+                    unpack4(make_uint2(rl[mj][k].x, rl[mj][k].y), rL, F16);
+                    unpack4(make_uint2(rl[mj][k].z, rl[mj][k].w), rL + 4, F16);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         acc[2 * k][mi][i] = ((acc[2 * k][mi][i] + b[i]) + rH[i]) + rL[i];
@@ -927,6 +1010,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                 }
             }
         }
+        PP_STAMP(3);  // bias + residual added: both halves' residual planes have arrived
         // 2. local sums over this workgroup's 192 columns
         float ml[4];
 #pragma unroll
@@ -960,6 +1044,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
             if (lg == 0) red2[wn * 256 + wm * 64 + mi * 16 + lr] = q;
         }
         __syncthreads();
+        PP_STAMP(4);  // local statistics done
         // 4.-6. exchange with the band mates, placement-independent and fence-free: every statistic travels as an
         // 8-byte {tag = epoch, value} granule written and polled with relaxed agent-scope atomics (write-through
         // stores, L1-bypassing loads; cdna_hip_programming.md Guideline 16, recipe R2: the data is the flag).
@@ -1009,6 +1094,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
             raise_fault(p.fault, !complete, DIDI_FAULT_LN_EXCHANGE);
         }
         __syncthreads();
+        PP_STAMP(5);  // band statistics collected
         // 7. normalise this workgroup's slice and store it
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -1035,12 +1121,23 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                     *reinterpret_cast<float4*>(p.C_f32 + o + 4) = make_float4(y[4], y[5], y[6], y[7]);
                 }
                 uint2 h0, l0, h1, l1;
-                if (dith) { split4_dither(y, h0, l0, dith); split4_dither(y + 4, h1, l1, dith); }
-                else { split4(y, h0, l0, p.f16); split4(y + 4, h1, l1, p.f16); }
+                if constexpr (F16) {  // packed truncating conversions (f16x2_dither), the offset that rounds to nearest when no dither is asked for
+                    const int d = dith ? dith : DIDI_RNE_AS_DITHER;
+                    split4_dither(y, h0, l0, d);
+                    split4_dither(y + 4, h1, l1, d);
+                } else {
+                    split4(y, h0, l0, 0);
+                    split4(y + 4, h1, l1, 0);
+                }
                 *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
                 *reinterpret_cast<uint4*>(p.C_lo + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
             }
         }
+        PP_STAMP(6);  // every store issued
+#ifdef DIDI_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        PP_STAMP(7);  // ... and drained
     }
 }
 
@@ -1157,6 +1254,9 @@ extern "C" int didi_gemm(const didi_gemm_args* a, void* stream) {
     p.fault = a->fault;
     DIDI_CHECK_ARG(a->act_dither >= 0 && a->act_dither < 8192);
     p.dither = a->act_dither;
+#ifdef DIDI_STAMPS
+    p.stamps = g_stamp_buf;
+#endif
     hipStream_t st = as_stream(stream);
     const int mode = pick_mode(p);
     const int big_tiles_n = cdiv(a->N, BBN);
@@ -1415,6 +1515,9 @@ extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const f
     p.ln_gamma = gamma; p.ln_beta = beta; p.ln_eps = eps; p.tiles_n = 4; p.fault = a->fault;
     DIDI_CHECK_ARG(a->act_dither >= 0 && a->act_dither < 8192);
     p.dither = a->act_dither;
+#ifdef DIDI_STAMPS
+    p.stamps = g_stamp_buf;
+#endif
     hipStream_t st = as_stream(stream);
     const int bands = cdiv(a->M, 256);
     if (epoch == 0) {  // stand-alone use: clear the granules, then tag 1

@@ -314,7 +314,10 @@ def test_gemm_ln_fused(ops, M, K, precision):
     want = torch.nn.functional.layer_norm(_gemm_ref(ar, wr, bias, None, r_used), (N,), g.double(), b.double(), 1e-12)
     assert rel_l2(y, want) <= 5e-6, rel_l2(y, want)  # measured 2.5e-6 (bf16x3: dropped lo*lo term), 3e-7 (one product)
     assert (y.cpu().double() - want).abs().max().item() <= 1e-3
-    assert torch.equal(y_hi.cpu(), y.cpu().to(pd)) and rel_l2(ops.join(y_hi, y_lo), y) <= 2e-5
+    # the hi plane is A nearest 16-bit value of y: fp16 epilogues of the 256x192 kernel round ties away from zero (packed
+    # truncating conversion with a half-ulp offset, common.hpp f16x2_dither), bf16 ones to even
+    d_hi, d_rne = (y_hi.float() - y).abs().cpu(), (y.to(pd).float() - y).abs().cpu()
+    assert bool((d_hi <= d_rne).all()) and rel_l2(ops.join(y_hi, y_lo), y) <= 2e-5
     # twice in a row in place (epoch 0: the call clears the statistics buffer itself), as the decoder engine uses it
     h_hi, h_lo = rp[0].clone(), rp[1].clone()
     ops.gemm_ln(a_hi, a_lo, w_hi, w_lo, bias.cuda(), (h_hi, h_lo), g.cuda(), b.cuda(), 1e-12, precision=precision, out=(h_hi, h_lo))

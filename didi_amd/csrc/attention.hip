@@ -283,7 +283,10 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
                 }
                 const int d0 = dt * 16 + lg * 4;
                 if (q < p.Sq && d0 < p.d) {
-                    const float o[4] = {acc[0] * rinv, acc[1] * rinv, acc[2] * rinv, acc[3] * rinv};
+                    // the fp32 products are made opaque before the 16-bit conversion: hipcc otherwise fuses product and conversion into one
+                    // v_fma_mixlo_f16 (a single rounding) in SOME instantiations, and the fused QKV form and attn_kernel would differ by an ulp in 1 of 50 000 values
+                    float o[4] = {acc[0] * rinv, acc[1] * rinv, acc[2] * rinv, acc[3] * rinv};
+                    asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
                     const size_t off = (size_t)q * p.ldo + d0;
                     if (ol) {
                         uint2 h2, l2;

@@ -137,7 +137,7 @@ int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi
 
 // ------------------------------------------------------------------ tuning switches (didi_set_option)
 static int g_options[DIDI_OPT_COUNT] = {/*GEMM_LN*/ 1, /*GEMM_SMALL*/ 1, /*GEMM_BIG*/ 1, /*GEMM_PP*/ 1, /*GEMM_MT*/ 4,
-                                        /*BIG_MIN_M*/ 2048, /*SMALL_MAX_M*/ 2048, /*X2_GEMMS*/ 63};
+                                        /*BIG_MIN_M*/ 2048, /*SMALL_MAX_M*/ 2048, /*X2_GEMMS*/ 63, /*FUSED_ATTN*/ 1};
 int didi_opt(int key) { return g_options[key]; }
 extern "C" int didi_set_option(int key, int value) {
     DIDI_CHECK_ARG(key >= 0 && key < DIDI_OPT_COUNT);
@@ -243,17 +243,38 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         const didi_decoder_layer& ly = dec->layers_host[l];
         const bool last = l == dec->L - 1;
         // --- causal self-attention block
-        TRY(gemm(ly.qkv, pc(0), M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, w.qkv_hi,
-                 x3 ? w.qkv_lo : nullptr, 3 * H, stream, &prof, w.small_ws, a->fault, dith));
         didi_attn_args at{};
         at.act_dither = dith;
-        at.B = a->B; at.heads = dec->heads; at.Sq = a->S; at.Sk = a->S; at.D = D; at.precision = attn_prec;
-        at.causal = 1; at.key_mask = nullptr;
-        at.Q_hi = w.qkv_hi; at.Q_lo = x3 ? w.qkv_lo : nullptr; at.ldq = 3 * H;
-        at.K_hi = w.qkv_hi + H; at.K_lo = x3 ? w.qkv_lo + H : nullptr; at.ldk = 3 * H;
-        at.V_hi = w.qkv_hi + 2 * H; at.V_lo = x3 ? w.qkv_lo + 2 * H : nullptr; at.ldv = 3 * H;
+        at.B = a->B; at.heads = dec->heads; at.D = D; at.precision = attn_prec;
         at.O_hi = w.att_hi; at.O_lo = x3 ? w.att_lo : nullptr; at.ldo = H;
-        TRY(didi_attention(&at, stream));
+        // one launch for the projections AND the attention where the shape allows (64 positions per dialog, 64-wide heads, fp16
+        // planes, one or two products): the [M, 3H] projection planes never reach memory
+        const bool fused_self = didi_opt(DIDI_OPT_FUSED_ATTN) != 0 && !x3 && ly.qkv.bias && ly.qkv.N == 3 * H &&
+                                didi_opt(DIDI_OPT_GEMM_BIG) != 0 && didi_opt(DIDI_OPT_GEMM_PP) != 0 && M >= didi_opt(DIDI_OPT_BIG_MIN_M) &&
+                                didi_qkv_self_attention_supported(M, H, dec->heads, a->S, ly.qkv.K, pc(0));
+        if (fused_self) {
+            didi_gemm_args g{};
+            g.fault = a->fault;
+            g.act_dither = dith;
+            g.M = M; g.N = 3 * H; g.K = ly.qkv.K; g.precision = pc(0);
+            g.A_hi = w.h_hi; g.A_lo = w.h_lo; g.lda = H;
+            g.W_hi = ly.qkv.w_hi; g.W_lo = ly.qkv.w_lo; g.ldw = ly.qkv.K;
+            g.bias = ly.qkv.bias; g.act = DIDI_ACT_NONE;
+            g.C_hi = w.att_hi; g.ldc = H;
+            prof.mark(stream);
+            const int rc_qkv = didi_qkv_self_attention(&g, dec->heads, a->S, 0.f, stream);
+            prof.mark(stream);
+            TRY(rc_qkv);
+        } else {
+            TRY(gemm(ly.qkv, pc(0), M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, w.qkv_hi,
+                     x3 ? w.qkv_lo : nullptr, 3 * H, stream, &prof, w.small_ws, a->fault, dith));
+            at.Sq = a->S; at.Sk = a->S;
+            at.causal = 1; at.key_mask = nullptr;
+            at.Q_hi = w.qkv_hi; at.Q_lo = x3 ? w.qkv_lo : nullptr; at.ldq = 3 * H;
+            at.K_hi = w.qkv_hi + H; at.K_lo = x3 ? w.qkv_lo + H : nullptr; at.ldk = 3 * H;
+            at.V_hi = w.qkv_hi + 2 * H; at.V_lo = x3 ? w.qkv_lo + 2 * H : nullptr; at.ldv = 3 * H;
+            TRY(didi_attention(&at, stream));
+        }
         TRY(gemm_ln(ly.attn_out, pc(1), fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln1_g, ly.ln1_b,
                     dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault, dith));
         // --- cross-attention block (K/V hoisted: didi_decoder_prepare_context)
@@ -261,7 +282,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         u16* q_lo = x3 ? w.qkv_lo : nullptr;
         TRY(gemm(ly.cq, pc(2), M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream, &prof, w.small_ws, a->fault, dith));
         const size_t kvoff = (size_t)l * Mc * 2 * H;
-        at.Sk = a->C; at.causal = 0; at.key_mask = a->ctx_mask; at.key_count = a->ctx_count;
+        at.Sq = a->S; at.Sk = a->C; at.causal = 0; at.key_mask = a->ctx_mask; at.key_count = a->ctx_count;
         at.Q_hi = q_hi; at.Q_lo = q_lo; at.ldq = H;
         at.K_hi = a->kv_hi + kvoff; at.K_lo = x3 ? a->kv_lo + kvoff : nullptr; at.ldk = 2 * H;
         at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;

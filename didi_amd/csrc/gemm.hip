@@ -74,6 +74,10 @@ struct GemmParams {
     unsigned long long* ln_stats;  // [tiles_m][tiles_n][256][2] granules {epoch, bits} of each tile's per-row (sum, M2)
     unsigned ln_epoch;             // tag of this launch's granules (>= 1; older tags and zero are stale)
     uint32_t* fault;               // device fault word (DIDI_FAULT_*) or null
+    float attn_scale;              // ATTN form: softmax scale * log2(e)
+    float attn_mask0;              // ATTN form: the additive mask of a visible key, 0.0f, as a run-time value: the scores are then
+                                   // fmaf(acc, scale, mask) exactly as in attn_kernel (a literal 0 would let the compiler fold the
+                                   // product into the subtraction of the row maximum: another rounding, 1 ulp in 2e-5 of the outputs)
     unsigned long long* stamps;    // diagnostic builds (-DDIDI_STAMPS) only: s_memtime stamps [workgroup][wave group][16]
     int dither;                    // fp16 activation-plane rounding dither of this launch (common.hpp f16x2_dither), 0 = RNE;
                                    // honoured by the one-product fp16 form of gemm_pp_kernel (the sampler's hot path)
@@ -647,9 +651,27 @@ __global__ void __launch_bounds__(BigGeom<MT>::THREADS, 2) gemm_big_kernel(GemmP
 // (L2 hits) one; every DMA wait is a counted vmcnt followed by a barrier before the first read.
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi);  // argmax order: larger value, then lower index
 
+// helpers of the ATTN form (the same LDS image and transposed reads as attention.hip)
+typedef short v4s_ __attribute__((ext_vector_type(4)));
+typedef short v8s_ __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int img64(int row, int ch) { return row * 128 + ((ch ^ (row & 7)) << 4); }
+__device__ __forceinline__ bf16x8 lds_tr8(const char* p0, const char* p1) {
+    const v4s_ a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_*)p0);
+    const v4s_ b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_*)p1);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 // AMAX: the rounding form.  No output tile: each row's (max, index) over this tile's 192 vocabulary columns goes to
 // p.partial[m][tile column]; the logits never leave the registers.
-template <int NPASS, bool F16, bool LN, bool AMAX = false>
+// ATTN: the fused self-attention form (didi_qkv_self_attention): BertSelfAttention's query / key / value projections AND its
+// causal attention in one launch, for dialogs of exactly 64 target positions and 64-wide heads.  A 256-row band is then four
+// whole dialogs and a 192-column tile is one head's [Q | K | V] (the weight rows of tile h are gathered as rows h*64.. of each
+// of the three projections: no permuted copy of the weights), so the workgroup that holds the tile's accumulators holds
+// everything the attention of (4 dialogs, head h) needs: Q, K, V go to LDS as fp16 (the stage buffers are free by then), and
+// each wave runs two 16-query blocks of one dialog exactly as attn_kernel does.  The [M, 3H] projection planes (75 MB written
+// and 75 MB read back per layer at the benchmark shape) and the attention launch disappear; the outputs are bit-identical to
+// didi_gemm + didi_attention (same conversions, same MFMA and summation order).
+template <int NPASS, bool F16, bool LN, bool AMAX = false, bool ATTN = false>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     using G = BigGeom<4>;
     constexpr int BKK = NPASS == 1 ? 64 : 32;
@@ -692,7 +714,9 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         // accumulator tiles 2k and 2k+1 then give every lane 8 CONSECUTIVE columns (epilogue8)
         const int wn_ = row / 96, rr_ = row % 96, ni_ = rr_ >> 4, rho_ = rr_ & 15;
         const int col = wn_ * 96 + 32 * (ni_ >> 1) + 8 * (rho_ >> 2) + 4 * (ni_ & 1) + (rho_ & 3);
-        src[j] = base + (size_t)(grp ? min(m0 + row, p.M - 1) * (size_t)p.lda : min(n0 + col, p.N - 1) * (size_t)p.ldw) + g * 8;
+        // ATTN: tile `tn` = head tn; its column c is row (c / 64) * H + tn * 64 + c % 64 of the stacked [query; key; value] weight
+        const int wrow = ATTN ? (col >> 6) * (p.N / 3) + (tile % p.tiles_n) * 64 + (col & 63) : min(n0 + col, p.N - 1);
+        src[j] = base + (size_t)(grp ? min(m0 + row, p.M - 1) * (size_t)p.lda : wrow * (size_t)p.ldw) + g * 8;
         qoff[j] = (grp ? 0 : W_OFF) + q * 1024;
     }
     const int nt = p.K / BKK;
@@ -755,7 +779,11 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     // the tile's 192 bias values ride along too (one 768-byte piece, wave 0): the epilogue then reads them from LDS instead of
     // opening with a dependent global load
     float* bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE + 8192);
-    if (!AMAX && p.bias && wave == 0 && lane < 48 && n0 + 4 * lane < p.N)
+    if constexpr (ATTN) {
+        if (wave == 0 && lane < 48)
+            glds16(reinterpret_cast<const u16*>(p.bias + ((4 * lane) >> 6) * (p.N / 3) + (tile % p.tiles_n) * 64 + ((4 * lane) & 63)),
+                   reinterpret_cast<char*>(bias_lds));
+    } else if (!AMAX && p.bias && wave == 0 && lane < 48 && n0 + 4 * lane < p.N)
         glds16(reinterpret_cast<const u16*>(p.bias + n0 + 4 * lane), reinterpret_cast<char*>(bias_lds));
     float* gamma_lds = bias_lds + 256;  // LayerNorm variant: gamma and beta of the tile's columns, waves 1 and 2
     float* beta_lds = bias_lds + 512;
@@ -824,6 +852,116 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #undef PP_READ
 #undef PP_MFMA
     PP_STAMP(2);  // K-loop done (this wave group)
+    if constexpr (ATTN) {
+        constexpr float NEG = -3.4028234663852886e38f;
+        f16_saturate_mode();
+        const int dith = NPASS == 1 ? p.dither : 0;
+        const int dq = dith ? dith : DIDI_RNE_AS_DITHER;
+        // ---- Q, K, V of (dialog wm, this head) -> LDS images [dialog][Q, K, V][64 rows][128 B], 16-byte chunks XOR-swizzled
+        float amax = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int row = mi * 16 + lr;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int nl = wn * 96 + 32 * k + 8 * lg;
+                const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + nl), b1 = *reinterpret_cast<const float4*>(bias_lds + nl + 4);
+                const float v[8] = {acc[2 * k][mi][0] + b0.x, acc[2 * k][mi][1] + b0.y, acc[2 * k][mi][2] + b0.z, acc[2 * k][mi][3] + b0.w,
+                                    acc[2 * k + 1][mi][0] + b1.x, acc[2 * k + 1][mi][1] + b1.y, acc[2 * k + 1][mi][2] + b1.z, acc[2 * k + 1][mi][3] + b1.w};
+                amax = amax2(amax2(amax2(amax2(amax, v[0], v[1]), v[2], v[3]), v[4], v[5]), v[6], v[7]);
+                const uint2 h0 = pack4_hi_dither(v, dq), h1 = pack4_hi_dither(v + 4, dq);
+                *reinterpret_cast<uint4*>(smem + ((wm * 3 + (nl >> 6)) * 64) * 128 + img64(row, (nl & 63) >> 3)) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            }
+        }
+        raise_fault(p.fault, amax > DIDI_F16_MAX, DIDI_FAULT_FP16_RANGE);
+        __syncthreads();
+        PP_STAMP(3);
+        // ---- causal attention: wave w takes dialog w / 2 and the query blocks {0, 3} or {1, 2} (1 + 4 or 2 + 3 key tiles)
+        const int dl = wave >> 1;
+        const char* Qs = smem + (dl * 3) * 8192;
+        const char* Ks = Qs + 8192;
+        const char* Vs = Ks + 8192;
+        const int trow = 4 * lg + (lr >> 2), tsub = 8 * (lr & 1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int qb = (wave & 1) ? 1 + u : 3 * u;  // wave-uniform
+            const int nkt = qb + 1, nks = (nkt + 1) >> 1;
+            const int q = qb * 16 + lr;
+            const bf16x8 qh0 = *reinterpret_cast<const bf16x8*>(Qs + img64(q, lg));
+            const bf16x8 qh1 = *reinterpret_cast<const bf16x8*>(Qs + img64(q, 4 + lg));
+            float sc[4][4];
+            float rmax = NEG, rsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt < nkt) {
+                    f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+                    s4 = mma16<true>(*reinterpret_cast<const bf16x8*>(Ks + img64(kt * 16 + lr, lg)), qh0, s4);
+                    s4 = mma16<true>(*reinterpret_cast<const bf16x8*>(Ks + img64(kt * 16 + lr, 4 + lg)), qh1, s4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sc[kt][r] = fmaf(s4[r], p.attn_scale, p.attn_mask0);
+                        if (kt == qb && kt * 16 + lg * 4 + r > q) sc[kt][r] = fminf(sc[kt][r], NEG);  // future keys (diagonal tile only)
+                    }
+                    rmax = fmaxf(rmax, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[kt][r] = -INFINITY;
+                }
+            }
+            rmax = fmaxf(rmax, __shfl_xor(rmax, 16, 64));
+            rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+            v8s_ ph[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                ph[s] = v8s_{0, 0, 0, 0, 0, 0, 0, 0};
+                if (s < nks) {
+                    float pr[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        pr[e] = __builtin_amdgcn_exp2f(sc[2 * s + (e >> 2)][e & 3] - rmax);
+                        rsum += pr[e];
+                    }
+                    if (dith) {
+                        const uint2 a0 = pack4_hi_dither(pr, dith), a1 = pack4_hi_dither(pr + 4, dith);
+                        ph[s] = __builtin_bit_cast(v8s_, make_uint4(a0.x, a0.y, a1.x, a1.y));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ph[s][e] = (short)f16_bits(pr[e]);
+                    }
+                }
+            }
+            rsum += __shfl_xor(rsum, 16, 64);
+            rsum += __shfl_xor(rsum, 32, 64);
+            const float rinv = 1.0f / rsum;
+            const int m = m0 + dl * 64 + q;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o4 = {0.f, 0.f, 0.f, 0.f};
+                const int cch = 2 * dt + ((lr & 3) >> 1);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (s < nks) {
+                        const bf16x8 vh = lds_tr8(Vs + img64(32 * s + trow, cch) + tsub, Vs + img64(32 * s + 16 + trow, cch) + tsub);
+                        o4 = mma16<true>(vh, __builtin_bit_cast(bf16x8, ph[s]), o4);
+                    }
+                }
+                if (m < p.M) {
+                    // the fp32 products are made opaque before the 16-bit conversion: hipcc otherwise fuses product and conversion into one
+                    // v_fma_mixlo_f16 (a single rounding) in SOME instantiations, and the fused QKV form and attn_kernel would differ by an ulp in 1 of 50 000 values
+                    float o[4] = {o4[0] * rinv, o4[1] * rinv, o4[2] * rinv, o4[3] * rinv};
+                    asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+                    *reinterpret_cast<uint2*>(p.C_hi + (size_t)m * p.ldc + (tile % p.tiles_n) * 64 + dt * 16 + lg * 4) =
+                        dith ? pack4_hi_dither(o, dith) : pack4_hi(o, 1);
+                }
+            }
+        }
+        PP_STAMP(6);
+#ifdef DIDI_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        PP_STAMP(7);
+        return;
+    }
     if constexpr (AMAX) {
         // lane (lr, lg) of wave (wm, wn) holds, for row wm*64 + mi*16 + lr, the columns wn*96 + 32k + 8lg + 4h + r of tile ni = 2k + h
         float best[4];
@@ -956,7 +1094,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const int n = n0 + wn * 96 + 32 * k + 8 * lg;
-                    if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi], gelu_tbl, amax, pre, rh[mj][k], rl[mj][k], bias_lds + (n - n0), dith);
+                    if (n + 8 <= p.N) epilogue8(p, m, n, acc[2 * k][mi], acc[2 * k + 1][mi], gelu_tbl, amax, pre, rh[mj][k], rl[mj][k], bias_lds + (n - n0),
+                                                   F16 ? (dith ? dith : DIDI_RNE_AS_DITHER) : 0);  // fp16 planes of this kernel round one way in every tile, edge tiles included
                     else if (n < p.N) epilogue4(p, m, n, acc[2 * k][mi][0], acc[2 * k][mi][1], acc[2 * k][mi][2], acc[2 * k][mi][3], amax);
                 }
             }
@@ -1192,9 +1331,9 @@ static bool gemm_pp_enabled() { return didi_opt(DIDI_OPT_GEMM_PP) != 0; }
 // Per-device set-up, done on the first call on each device: the > 64 KiB dynamic-LDS opt-ins of every big-tile kernel
 // (function attributes live per device) and the device's CU count.  Keyed by the CURRENT device, so a process that
 // drives several GPUs gets each one's own values.
-template <int NPASS, bool F16, bool LN, bool AMAX>
+template <int NPASS, bool F16, bool LN, bool AMAX, bool ATTN = false>
 static bool opt_in_pp() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<NPASS, F16, LN, AMAX>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<NPASS, F16, LN, AMAX, ATTN>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess;
 }
 struct DeviceInfo { int state; int ncu; };  // state: 0 = not probed, 1 = ready, -1 = failed
@@ -1214,6 +1353,7 @@ static const DeviceInfo* device_info() {
         ok = ok && opt_in_pp<3, false, false, true>() && opt_in_pp<1, false, false, true>() && opt_in_pp<1, true, false, true>();
         ok = ok && opt_in_pp<2, true, false, false>() && opt_in_pp<2, true, true, false>() && opt_in_pp<2, true, false, true>();
         ok = ok && opt_in_pp<3, true, false, false>() && opt_in_pp<3, true, false, true>() && opt_in_pp<3, true, true, false>();
+        ok = ok && opt_in_pp<1, true, false, false, true>() && opt_in_pp<2, true, false, false, true>();
         int c = 0;
         ok = ok && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0;
         d.ncu = c;
@@ -1297,6 +1437,42 @@ extern "C" int didi_gemm(const didi_gemm_args* a, void* stream) {
         else if (p.f16) gemm_kernel<0, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
         else gemm_kernel<0, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
     }
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ query / key / value projections + causal self-attention
+extern "C" int didi_qkv_self_attention_supported(int M, int H, int heads, int S, int K, int precision) {
+    return (precision == DIDI_PREC_FP16 || precision == DIDI_PREC_FP16X2) && S == 64 && heads > 0 && H == heads * 64 && M >= 2048 &&
+           M % 64 == 0 && K % 64 == 0 && K >= 128 && 3 * H == heads * BBN;
+}
+
+extern "C" int didi_qkv_self_attention(const didi_gemm_args* a, int heads, int S, float scale, void* stream) {
+    DIDI_CHECK_ARG(a && a->A_hi && a->W_hi && a->bias && a->C_hi && a->M >= 0 && a->N > 0 && a->N % 3 == 0 && a->K > 0 && scale >= 0.f);
+    DIDI_CHECK_ARG(a->act == DIDI_ACT_NONE && !a->C_f32 && !a->C_lo && !a->R_f32 && !a->R_hi && !a->R_lo);
+    const int H = a->N / 3;
+    if (!didi_qkv_self_attention_supported(a->M, H, heads, S, a->K, a->precision)) return DIDI_ERR_UNSUPPORTED;
+    DIDI_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K && a->ldc % 4 == 0 && a->ldc >= H);
+    DIDI_CHECK_ARG(al16(a->A_hi) && al16(a->W_hi) && al16(a->W_lo) && al16(a->bias) && al8(a->C_hi));
+    DIDI_CHECK_ARG(a->act_dither >= 0 && a->act_dither < 8192);
+    if (a->M == 0) return DIDI_OK;
+    if (!allow_big_lds()) return DIDI_ERR_LAUNCH;
+    GemmParams p{};
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    int rc = fill_operands(p, a->precision, a->A_hi, a->A_lo, a->W_hi, a->W_lo);
+    if (rc != DIDI_OK) return rc;
+    p.lda = a->lda; p.ldw = a->ldw; p.bias = a->bias; p.act = DIDI_ACT_NONE;
+    p.C_hi = a->C_hi; p.ldc = a->ldc; p.fault = a->fault; p.dither = a->act_dither;
+    p.attn_scale = 1.4426950408889634f * (scale > 0.f ? scale : 0.125f);  // softmax scale * log2(e); 0 = 1 / sqrt(64)
+    p.attn_mask0 = 0.0f;
+#ifdef DIDI_STAMPS
+    p.stamps = g_stamp_buf;
+#endif
+    p.tiles_m = cdiv(p.M, 256); p.tiles_n = heads;
+    const int grid = p.tiles_m * p.tiles_n;
+    hipStream_t st = as_stream(stream);
+    if (p.npass == 2) gemm_pp_kernel<2, true, false, false, true><<<grid, 512, PP_LDS_BYTES, st>>>(p);
+    else gemm_pp_kernel<1, true, false, false, true><<<grid, 512, PP_LDS_BYTES, st>>>(p);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

@@ -74,7 +74,9 @@ enum {
     DIDI_OPT_X2_GEMMS = 7,     /* bit mask of the decoder GEMMs that multiply the weights' remainder plane in an FP16X2 call: bit 0 qkv,
                                   1 attention output, 2 cross-attention query, 3 cross-attention output, 4 FFN up, 5 FFN down; the others
                                   run one product there.  Default 63 (all) */
-    DIDI_OPT_COUNT = 8
+    DIDI_OPT_FUSED_ATTN = 8,   /* 1 (default): the engine runs a layer's query/key/value projections and its causal self-attention as ONE
+                                  launch where didi_qkv_self_attention supports the shape; 0: didi_gemm + didi_attention */
+    DIDI_OPT_COUNT = 9
 };
 int didi_set_option(int key, int value);
 int didi_get_option(int key, int* value);
@@ -243,6 +245,21 @@ int didi_gemm_ln_supported(int M, int N, int K, int precision);
 size_t didi_gemm_ln_stats_bytes(int M);
 int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, uint16_t* y_hi,
                  uint16_t* y_lo, float* y_f32, void* stats, uint32_t epoch, void* stream);
+
+/* BertSelfAttention in ONE launch (HF:models/bert/modeling_bert.py:164-203: `query`, `key`, `value` Linears :175-177, then
+ * eager_attention_forward :111-136 with the causal mask of is_decoder=True :696-702 and no padding mask, as DiDi.forward
+ * calls the decoder, src/diffusion/model.py:193-197):
+ *   O[b, q, head] = softmax(causal(Q K^T / sqrt(64))) V,   [Q | K | V] = A W^T + bias
+ * for dialogs of exactly S = 64 target positions and 64-wide heads (BertConfig defaults: 768 / 12), M = B * 64 rows.  `a` is the
+ * didi_gemm_args of the projection: W = the stacked [query; key; value] weight [3H, K] as the engine keeps it, bias [3H],
+ * precision DIDI_PREC_FP16 or DIDI_PREC_FP16X2 (the attention itself is one product either way), C_hi = O [M, ldc >= H] fp16
+ * plane, nothing else set (no activation, residual, C_f32, C_lo).  A 256-row tile band is four whole dialogs and a 192-column
+ * tile one head's Q, K and V, so the projections never leave the chip: same results, bit for bit, as didi_gemm into
+ * [M, 3H] planes followed by didi_attention(causal) -- minus 2 x 6 B per row and column of HBM traffic and one launch.
+ * scale: softmax scale, 0 = 1/8.  didi_qkv_self_attention_supported: S == 64, H == 64 * heads, M >= 2048, M % 64 == 0,
+ * K % 64 == 0; otherwise DIDI_ERR_UNSUPPORTED and the caller runs the two launches. */
+int didi_qkv_self_attention_supported(int M, int H, int heads, int S, int K, int precision);
+int didi_qkv_self_attention(const didi_gemm_args* a, int heads, int S, float scale, void* stream);
 
 /* Small batches (M < 2048 rows: interactive use, a handful of dialogs).  The same arithmetic as didi_gemm (+ an
  * optional LayerNorm over the N output columns: gamma/beta non-NULL, as didi_gemm_ln), organised for latency: K is split

@@ -464,6 +464,8 @@ def fullsize_cases(only=None):
              "out.top2_gap": (top2[..., 0] - top2[..., 1]).contiguous(), "out.x0": x0_seen[0].contiguous(),
              # the schedule buffers as a checkpoint would carry them: configure_schedule's last bits differ between host CPUs
              "w.sigmas": sd["sigmas"].contiguous(), "w.std_0": sd["std_0"].reshape(1).contiguous()}
+        if weights == "trained_like":  # its exp() on the LayerNorm gammas is libm-dependent too
+            t.update({"w." + k: v.contiguous() for k, v in sd.items() if k.startswith("decoder.") and k.endswith("LayerNorm.weight")})
         for k, c in zip(keep, m.calls):
             t[f"xt.{k}"] = c[:Bx].contiguous()
         run = dict(mode=mode, step_freq=f, max_len=S, weights=weights, weight_seed=1234, batch_seed=11,

@@ -35,7 +35,7 @@ def main():
     sd = synthetic_state_dict(cfg, seed=run["weight_seed"])
     if run["weights"] == "trained_like":
         sd = trained_like(sd)
-    sd["sigmas"], sd["std_0"] = t["w.sigmas"], t["w.std_0"].reshape(())
+    sd.update({k[2:]: (v.reshape(()) if k == "w.std_0" else v) for k, v in t.items() if k.startswith("w.")})
     assert sd_hash(sd) == meta["weights_sha256"]
     Bg, Bo, Bx, S = run["B_gpu"], run["B_ref"], run["B_xt"], run["max_len"]
     ids, mask = synthetic_batch(Bg, 64, cfg.vocab, seed=run["batch_seed"])

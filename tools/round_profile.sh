@@ -18,6 +18,10 @@ for P in fp16 fp16x2 fp16x3; do
   python3 tools/pmc_traffic.py $(find $O/${TAG}_pmc_${P}_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/${TAG}_pmc_${P}_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/gemm_traffic_${P}.json
   rm -rf $O/${TAG}_pmc_${P}_FETCH_SIZE $O/${TAG}_pmc_${P}_WRITE_SIZE
 done
+# L2 hit rate / fabric request mix per kernel (tools/pmc_l2.py): what the counters can say about the re-streamed operands
+timeout -s KILL 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum --output-format csv -d $O/${TAG}_pmc_l2 -o p -- python3 bench.py --diffusion-steps 3 --steps 1 --warmup 0 --no-cpu-baseline --precision fp16 > /dev/null 2>&1
+python3 tools/pmc_l2.py $(find $O/${TAG}_pmc_l2 -name "*counter_collection.csv" | head -1) $O/${TAG}_l2_counters.json | tee $O/${TAG}_l2_counters.txt
+rm -rf $O/${TAG}_pmc_l2
 # the other BASELINE configurations as bench lines (single GPU): configs[2] at its per-GPU shape, configs[3] shortened to T = 100
 # (x 20 for T = 2000), configs[4] = the training step
 timeout -k 10 300 python3 bench.py --preset configs2 --no-cpu-baseline > $O/${TAG}_bench_configs2.log 2>&1

@@ -94,12 +94,17 @@ int gemm(const didi_linear& w, int precision, int M, const u16* a_hi, const u16*
     return rc;
 }
 
+static bool gemm_ln_fuses(const didi_linear& w, int precision, int M) {
+    return didi_opt(DIDI_OPT_GEMM_LN) != 0 && didi_gemm_ln_supported(M, w.N, w.K, precision) && w.bias;
+}
+
 // output projection + residual + LayerNorm: the fused kernel where it supports the shape (H = 768, M >= 2048),
 // else GEMM -> fp32 tmp -> LayerNorm.  `epoch` tags this launch's statistics in the shared `stats` buffer.
 int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi, const u16* a_lo, int lda, const u16* r_hi,
             const u16* r_lo, int ldr, float* tmp, void* stats, uint32_t epoch, const float* gamma, const float* beta, float eps,
-            u16* y_hi, u16* y_lo, float* y_f32, void* stream, Prof* prof, void* small_ws, uint32_t* fault, int dither = 0) {
+            u16* y_hi, u16* y_lo, float* y_f32, void* stream, Prof* prof, void* small_ws, uint32_t* fault, int dither = 0, int hi_only = 0) {  // hi_only: bit 0 the residual, bit 1 the output
     const bool fuse = didi_opt(DIDI_OPT_GEMM_LN) != 0;  // 0: A/B switch back to GEMM + LayerNorm
+    if (hi_only && !gemm_ln_fuses(w, precision, M)) return DIDI_ERR_UNSUPPORTED;  // the caller checked: the other forms read r_lo
     if (fuse && didi_gemm_ln_supported(M, w.N, w.K, precision) && w.bias) {
         didi_gemm_args g{};
         g.fault = fault;
@@ -108,9 +113,9 @@ int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi
         g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
         g.W_hi = w.w_hi; g.W_lo = w.w_lo; g.ldw = w.K;
         g.bias = w.bias; g.act = DIDI_ACT_NONE;
-        g.R_hi = r_hi; g.R_lo = r_lo; g.ldr = ldr;
+        g.R_hi = r_hi; g.R_lo = (hi_only & 1) ? nullptr : r_lo; g.ldr = ldr;
         if (prof) prof->mark(stream);
-        const int rc = didi_gemm_ln(&g, gamma, beta, eps, y_hi, y_lo, y_f32, stats, epoch, stream);
+        const int rc = didi_gemm_ln(&g, gamma, beta, eps, y_hi, (hi_only & 2) ? nullptr : y_lo, y_f32, stats, epoch, stream);
         if (prof) prof->mark(stream);
         return rc;
     }
@@ -137,13 +142,14 @@ int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi
 
 // ------------------------------------------------------------------ tuning switches (didi_set_option)
 static int g_options[DIDI_OPT_COUNT] = {/*GEMM_LN*/ 1, /*GEMM_SMALL*/ 1, /*GEMM_BIG*/ 1, /*GEMM_PP*/ 1, /*GEMM_MT*/ 4,
-                                        /*BIG_MIN_M*/ 2048, /*SMALL_MAX_M*/ 2048, /*X2_GEMMS*/ 63, /*FUSED_ATTN*/ 1};
+                                        /*BIG_MIN_M*/ 2048, /*SMALL_MAX_M*/ 2048, /*X2_GEMMS*/ 63, /*FUSED_ATTN*/ 3, /*HI_RESIDUAL*/ 0};
 int didi_opt(int key) { return g_options[key]; }
 extern "C" int didi_set_option(int key, int value) {
     DIDI_CHECK_ARG(key >= 0 && key < DIDI_OPT_COUNT);
     if (key == DIDI_OPT_GEMM_MT) DIDI_CHECK_ARG(value == 2 || value == 4);
     if (key == DIDI_OPT_BIG_MIN_M || key == DIDI_OPT_SMALL_MAX_M) DIDI_CHECK_ARG(value >= 0);
     if (key == DIDI_OPT_X2_GEMMS) DIDI_CHECK_ARG(value >= 0 && value <= 63);
+    if (key == DIDI_OPT_FUSED_ATTN) DIDI_CHECK_ARG(value >= 0 && value <= 3);
     g_options[key] = value;
     return DIDI_OK;
 }
@@ -238,6 +244,13 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
     // statistic granules of the fused projection+LayerNorm launches: cleared once, then one epoch per launch
     if (hipMemsetAsync(w.ln_stats, 0, w.ln_stats_bytes, as_stream(stream)) != hipSuccess) return DIDI_ERR_LAUNCH;
     uint32_t epoch = 0;
+    // one-product fp16 calls (DIDI_OPT_HI_RESIDUAL): the residual stream between the fused projection + LayerNorm launches travels
+    // as its hi plane alone -- those launches are bound by the bytes of their epilogue, and the remainder plane is half of them
+    bool hi_res = didi_opt(DIDI_OPT_HI_RESIDUAL) != 0 && prec == DIDI_PREC_FP16;
+    for (int l = 0; l < dec->L && hi_res; ++l) {
+        const didi_decoder_layer& ly = dec->layers_host[l];
+        hi_res = gemm_ln_fuses(ly.attn_out, prec, M) && gemm_ln_fuses(ly.cross_out, prec, M) && gemm_ln_fuses(ly.ffn_down, prec, M);
+    }
 
     for (int l = 0; l < dec->L; ++l) {
         const didi_decoder_layer& ly = dec->layers_host[l];
@@ -249,7 +262,7 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         at.O_hi = w.att_hi; at.O_lo = x3 ? w.att_lo : nullptr; at.ldo = H;
         // one launch for the projections AND the attention where the shape allows (64 positions per dialog, 64-wide heads, fp16
         // planes, one or two products): the [M, 3H] projection planes never reach memory
-        const bool fused_self = didi_opt(DIDI_OPT_FUSED_ATTN) != 0 && !x3 && ly.qkv.bias && ly.qkv.N == 3 * H &&
+        const bool fused_self = (didi_opt(DIDI_OPT_FUSED_ATTN) & 1) != 0 && !x3 && ly.qkv.bias && ly.qkv.N == 3 * H &&
                                 didi_opt(DIDI_OPT_GEMM_BIG) != 0 && didi_opt(DIDI_OPT_GEMM_PP) != 0 && M >= didi_opt(DIDI_OPT_BIG_MIN_M) &&
                                 didi_qkv_self_attention_supported(M, H, dec->heads, a->S, ly.qkv.K, pc(0));
         if (fused_self) {
@@ -276,26 +289,46 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
             TRY(didi_attention(&at, stream));
         }
         TRY(gemm_ln(ly.attn_out, pc(1), fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln1_g, ly.ln1_b,
-                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault, dith));
+                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault, dith, hi_res ? 3 : 0));
         // --- cross-attention block (K/V hoisted: didi_decoder_prepare_context)
         u16* q_hi = w.qkv_hi;
         u16* q_lo = x3 ? w.qkv_lo : nullptr;
-        TRY(gemm(ly.cq, pc(2), M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream, &prof, w.small_ws, a->fault, dith));
         const size_t kvoff = (size_t)l * Mc * 2 * H;
-        at.Sq = a->S; at.Sk = a->C; at.causal = 0; at.key_mask = a->ctx_mask; at.key_count = a->ctx_count;
-        at.Q_hi = q_hi; at.Q_lo = q_lo; at.ldq = H;
-        at.K_hi = a->kv_hi + kvoff; at.K_lo = x3 ? a->kv_lo + kvoff : nullptr; at.ldk = 2 * H;
-        at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;
-        TRY(didi_attention(&at, stream));
+        // the query projection AND the attention over the hoisted K / V in one launch, under the same conditions as above
+        const bool fused_cross = (didi_opt(DIDI_OPT_FUSED_ATTN) & 2) != 0 && !x3 && ly.cq.bias && ly.cq.N == H &&
+                                 didi_opt(DIDI_OPT_GEMM_BIG) != 0 && didi_opt(DIDI_OPT_GEMM_PP) != 0 && M >= didi_opt(DIDI_OPT_BIG_MIN_M) &&
+                                 didi_q_cross_attention_supported(M, H, dec->heads, a->S, a->C, ly.cq.K, pc(2));
+        if (fused_cross) {
+            didi_gemm_args g{};
+            g.fault = a->fault;
+            g.act_dither = dith;
+            g.M = M; g.N = H; g.K = ly.cq.K; g.precision = pc(2);
+            g.A_hi = w.h_hi; g.A_lo = w.h_lo; g.lda = H;
+            g.W_hi = ly.cq.w_hi; g.W_lo = ly.cq.w_lo; g.ldw = ly.cq.K;
+            g.bias = ly.cq.bias; g.act = DIDI_ACT_NONE;
+            g.C_hi = w.att_hi; g.ldc = H;
+            prof.mark(stream);
+            const int rc_cq = didi_q_cross_attention(&g, a->kv_hi + kvoff, a->kv_hi + kvoff + H, 2 * H, a->ctx_mask, a->ctx_count, dec->heads,
+                                                     a->S, a->C, 0.f, stream);
+            prof.mark(stream);
+            TRY(rc_cq);
+        } else {
+            TRY(gemm(ly.cq, pc(2), M, w.h_hi, w.h_lo, H, DIDI_ACT_NONE, nullptr, nullptr, 0, nullptr, q_hi, q_lo, H, stream, &prof, w.small_ws, a->fault, dith));
+            at.Sq = a->S; at.Sk = a->C; at.causal = 0; at.key_mask = a->ctx_mask; at.key_count = a->ctx_count;
+            at.Q_hi = q_hi; at.Q_lo = q_lo; at.ldq = H;
+            at.K_hi = a->kv_hi + kvoff; at.K_lo = x3 ? a->kv_lo + kvoff : nullptr; at.ldk = 2 * H;
+            at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;
+            TRY(didi_attention(&at, stream));
+        }
         TRY(gemm_ln(ly.cross_out, pc(3), fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln2_g, ly.ln2_b,
-                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault, dith));
+                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault, dith, hi_res ? 3 : 0));
         // --- feed-forward block
         TRY(gemm(ly.ffn_up, pc(4), M, w.h_hi, w.h_lo, H, DIDI_ACT_GELU, nullptr, nullptr, 0, nullptr, w.ffn_hi,
                  ffn_lo ? w.ffn_lo : nullptr, I, stream, &prof, w.small_ws, a->fault, dith));
         u16* o_hi = last && a->x0_hi ? a->x0_hi : w.h_hi;
         u16* o_lo = last && a->x0_hi ? a->x0_lo : w.h_lo;
         TRY(gemm_ln(ly.ffn_down, pc(5), fmt, M, w.ffn_hi, w.ffn_lo, I, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln3_g, ly.ln3_b,
-                    dec->ln_eps, o_hi, o_lo, last ? a->x0_f32 : nullptr, stream, &prof, w.small_ws, a->fault, dith));
+                    dec->ln_eps, o_hi, o_lo, last ? a->x0_f32 : nullptr, stream, &prof, w.small_ws, a->fault, dith, hi_res ? (last ? 1 : 3) : 0));
     }
     if (a->prof_used_host) *a->prof_used_host = prof.used;
     return DIDI_OK;

@@ -74,6 +74,9 @@ struct GemmParams {
     unsigned long long* ln_stats;  // [tiles_m][tiles_n][256][2] granules {epoch, bits} of each tile's per-row (sum, M2)
     unsigned ln_epoch;             // tag of this launch's granules (>= 1; older tags and zero are stale)
     uint32_t* fault;               // device fault word (DIDI_FAULT_*) or null
+    const u16 *attn_K, *attn_V;    // ATTN == 2 (cross-attention): hoisted K / V planes [B * 64][attn_ldkv], head h at column h * 64
+    int attn_ldkv, attn_B;
+    const int32_t *attn_mask, *attn_count;  // [B][64] key mask (0 = padded) or null; [B] visible-key counts or null
     float attn_scale;              // ATTN form: softmax scale * log2(e)
     float attn_mask0;              // ATTN form: the additive mask of a visible key, 0.0f, as a run-time value: the scores are then
                                    // fmaf(acc, scale, mask) exactly as in attn_kernel (a literal 0 would let the compiler fold the
@@ -95,7 +98,7 @@ extern "C" void didi_debug_set_stamps(void* buf) { g_stamp_buf = reinterpret_cas
         if (p.stamps && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) & 3) == 0) {                          \
             unsigned long long* s_ = p.stamps + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 8)) * 16;          \
             s_[i] = __builtin_amdgcn_s_memtime();                                                            \
-            if ((i) == 0) s_[14] = __builtin_amdgcn_s_memrealtime();                                         \
+            if ((i) == 0) { s_[14] = __builtin_amdgcn_s_memrealtime(); s_[12] = t_entry; }                   \
             if ((i) == 7) s_[15] = __builtin_amdgcn_s_memrealtime();                                         \
         }                                                                                                    \
     } while (0)
@@ -108,6 +111,17 @@ __device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((c
 
 __device__ __forceinline__ void glds16(const u16* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)lds_dst, 16, 0, 0);
+}
+// The same instruction out of the compiler's sight.  hipcc tracks the builtin as a pending write to LDS and puts
+// s_waitcnt vmcnt(0) in front of later LDS reads it cannot prove disjoint (float and transposed reads in particular): right
+// where everything is waited for anyway, fatal for a loop that keeps the NEXT buffer's pieces (and its stores) in flight across
+// reads of the current one.  Every use is followed by a hand-counted s_waitcnt vmcnt and a barrier before the first read.
+__device__ __forceinline__ void glds16_raw(const u16* src, char* lds_dst) {
+    const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void*)lds_dst);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m) : "memory", "m0");
+#pragma clang diagnostic pop
 }
 
 // ------------------------------------------------------------------ LDS-DMA main loop
@@ -652,6 +666,27 @@ __global__ void __launch_bounds__(BigGeom<MT>::THREADS, 2) gemm_big_kernel(GemmP
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi);  // argmax order: larger value, then lower index
 
 // helpers of the ATTN form (the same LDS image and transposed reads as attention.hip)
+// LDS map of the cross-attention form (ATTN == 2): Q images at 0 and K / V buffers 1, 2 inside the stage area (free when the
+// K-loop ends), K / V buffer 0, the key bias and the tile's bias values behind it
+#define XA_KV0 (2 * BigGeom<4>::STAGE)
+#define XA_KV1 49152
+#define XA_MB (XA_KV0 + 32768)
+#define XA_BIAS (XA_MB + 1024)
+#define XA_LDS_BYTES (XA_BIAS + 768)
+static_assert(XA_KV1 + 2 * 32768 == XA_KV0, "K / V buffers 1 and 2 end where the stages end");
+__device__ __forceinline__ void xa_wait_vm(int n) {  // s_waitcnt vmcnt(n), n wave-uniform and <= 8
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
 typedef short v4s_ __attribute__((ext_vector_type(4)));
 typedef short v8s_ __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ int img64(int row, int ch) { return row * 128 + ((ch ^ (row & 7)) << 4); }
@@ -671,7 +706,7 @@ __device__ __forceinline__ bf16x8 lds_tr8(const char* p0, const char* p1) {
 // each wave runs two 16-query blocks of one dialog exactly as attn_kernel does.  The [M, 3H] projection planes (75 MB written
 // and 75 MB read back per layer at the benchmark shape) and the attention launch disappear; the outputs are bit-identical to
 // didi_gemm + didi_attention (same conversions, same MFMA and summation order).
-template <int NPASS, bool F16, bool LN, bool AMAX = false, bool ATTN = false>
+template <int NPASS, bool F16, bool LN, bool AMAX = false, int ATTN = 0>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     using G = BigGeom<4>;
     constexpr int BKK = NPASS == 1 ? 64 : 32;
@@ -679,6 +714,9 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     constexpr int NYP = NPASS == 2 ? 4 : 8;             // activation pieces per wave of group Y (fp16x2 stages no A_lo tile)
     constexpr int W_OFF = G::A_BYTES, LO_A = G::A_BYTES / 2, LO_W = 12288, STAGE = G::STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef DIDI_STAMPS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();  // the wave's first instructions (slot 13, 100 MHz)
+#endif
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * BBN;
     const int tid = threadIdx.x;
@@ -715,7 +753,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         const int wn_ = row / 96, rr_ = row % 96, ni_ = rr_ >> 4, rho_ = rr_ & 15;
         const int col = wn_ * 96 + 32 * (ni_ >> 1) + 8 * (rho_ >> 2) + 4 * (ni_ & 1) + (rho_ & 3);
         // ATTN: tile `tn` = head tn; its column c is row (c / 64) * H + tn * 64 + c % 64 of the stacked [query; key; value] weight
-        const int wrow = ATTN ? (col >> 6) * (p.N / 3) + (tile % p.tiles_n) * 64 + (col & 63) : min(n0 + col, p.N - 1);
+        const int wrow = ATTN == 1 ? (col >> 6) * (p.N / 3) + (tile % p.tiles_n) * 64 + (col & 63) : min(n0 + col, p.N - 1);
         src[j] = base + (size_t)(grp ? min(m0 + row, p.M - 1) * (size_t)p.lda : wrow * (size_t)p.ldw) + g * 8;
         qoff[j] = (grp ? 0 : W_OFF) + q * 1024;
     }
@@ -778,8 +816,51 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     if (use_lut) glds16(reinterpret_cast<const u16*>(didi_gelu_table) + wave * 512 + lane * 8, smem + 2 * STAGE + wave * 1024);
     // the tile's 192 bias values ride along too (one 768-byte piece, wave 0): the epilogue then reads them from LDS instead of
     // opening with a dependent global load
-    float* bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE + 8192);
-    if constexpr (ATTN) {
+    float* bias_lds = reinterpret_cast<float*>(smem + (ATTN == 2 ? XA_BIAS : 2 * STAGE + 8192));
+    // cross-attention form: visible keys per dialog of the band (right-padded contexts: keys from the count on are never loaded nor
+    // multiplied), and the K / V pieces of phase ph = (pair of dialogs ph / 3, head 3 tn + ph % 3) into buffer ph % 3: piece q of
+    // 32 = (dialog q >> 4, K or V (q >> 3) & 1, rows 8 (q & 7) ..); wave w issues pieces 4 w .. 4 w + 3 and gets back how many
+    // it issued (rows at or past ceil32(count) are not fetched: their key tiles are skipped)
+    const int b0 = m0 >> 6;
+    int xa_kc[4] = {64, 64, 64, 64}, xa_nkt[4] = {4, 4, 4, 4};
+    float xa_mbv = 0.f;
+    auto xa_buf = [](int i) { return i == 0 ? XA_KV0 : XA_KV1 + (i - 1) * 32768; };
+    auto xa_issue_kv = [&](int ph) -> int {
+        const int hf = ph >= 3, hh = ph - 3 * hf;
+        char* buf = smem + xa_buf(ph % 3);
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = wave * 4 + j;
+            const int d2 = q >> 4, isv = (q >> 3) & 1, r0 = (q & 7) * 8;
+            const int d4 = hf * 2 + d2;
+            const int rows = ((d4 == 0 ? xa_nkt[0] : d4 == 1 ? xa_nkt[1] : d4 == 2 ? xa_nkt[2] : xa_nkt[3]) + 1) >> 1 << 5;
+            if (r0 < rows) {
+                const int row = r0 + (lane >> 3), slot = lane & 7;
+                const int bb = min(b0 + d4, p.attn_B - 1);
+                const u16* s_ = (isv ? p.attn_V : p.attn_K) + ((size_t)bb * 64 + row) * p.attn_ldkv + (3 * (tile % p.tiles_n) + hh) * 64 + ((slot ^ (row & 7)) << 3);
+                glds16_raw(s_, buf + q * 1024);
+                ++n;
+            }
+        }
+        return n;
+    };
+    if constexpr (ATTN == 2) {
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4) {
+            if (p.attn_count && b0 + d4 < p.attn_B) {
+                const int c = __builtin_amdgcn_readfirstlane(p.attn_count[b0 + d4]);
+                if (c > 0 && c < 64) xa_kc[d4] = c;
+            }
+            xa_nkt[d4] = (xa_kc[d4] + 15) >> 4;
+        }
+        if (tid < 256) {  // waves 0-3: the additive key bias of (dialog wave, key lane): 0, NEG (masked) or -inf (past the count)
+            const int kc_ = wave == 0 ? xa_kc[0] : wave == 1 ? xa_kc[1] : wave == 2 ? xa_kc[2] : xa_kc[3];
+            if (lane >= kc_) xa_mbv = -INFINITY;
+            else if (p.attn_mask && b0 + wave < p.attn_B && p.attn_mask[(size_t)(b0 + wave) * 64 + lane] == 0) xa_mbv = -3.4028234663852886e38f;
+        }
+    }
+    if constexpr (ATTN == 1) {
         if (wave == 0 && lane < 48)
             glds16(reinterpret_cast<const u16*>(p.bias + ((4 * lane) >> 6) * (p.N / 3) + (tile % p.tiles_n) * 64 + ((4 * lane) & 63)),
                    reinterpret_cast<char*>(bias_lds));
@@ -791,6 +872,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         if (wave == 1 && lane < 48) glds16(reinterpret_cast<const u16*>(p.ln_gamma + n0 + 4 * lane), reinterpret_cast<char*>(gamma_lds));
         if (wave == 2 && lane < 48) glds16(reinterpret_cast<const u16*>(p.ln_beta + n0 + 4 * lane), reinterpret_cast<char*>(beta_lds));
     }
+    if constexpr (ATTN == 2) (void)xa_issue_kv(0);  // behind the stages: in flight under the K-loop (whose waits cover it)
     PP_STAMP(0);
     // tile 0 must have landed before the first read; tile 1 stays in flight (first waits: end of B2_0)
     if (grp == 0) {
@@ -852,7 +934,182 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #undef PP_READ
 #undef PP_MFMA
     PP_STAMP(2);  // K-loop done (this wave group)
-    if constexpr (ATTN) {
+    if constexpr (ATTN == 2) {
+        // ---- BertCrossAttention: the tile's 192 columns are the queries of heads 3 tn .. 3 tn + 2 for the band's four dialogs; K and
+        // V come from the hoisted cache [B * 64][ldkv] (K at column head * 64, V a plane offset further).  Six phases of (two
+        // dialogs, one head), three K / V buffers of 32 KB: phase 0's arrives under the K-loop (its buffer lies behind the stages),
+        // phases 1 and 2 are issued when the loop ends, phase i + 2 when phase i starts; every wait is a COUNTED vmcnt (the
+        // outputs of phase i - 1 are stored at the start of phase i, so neither a store nor a younger K / V piece is ever
+        // waited for).  Each wave runs ONE 16-query block per phase exactly as attn_kernel does (masked / padded keys, key
+        // counts, summation order: bit-identical outputs).
+        constexpr float NEG = -3.4028234663852886e38f;
+        f16_saturate_mode();
+        const int dith = NPASS == 1 ? p.dither : 0;
+        const int dq = dith ? dith : DIDI_RNE_AS_DITHER;
+        const int tn = tile % p.tiles_n;
+        char* Qimg = smem;  // [2 dialogs][3 heads][64 rows][128 B]
+        float* mb = reinterpret_cast<float*>(smem + XA_MB);  // [4 dialogs][64 keys] additive key bias
+        if (tid < 256) mb[tid] = xa_mbv;
+        const int n1 = xa_issue_kv(1), n2 = xa_issue_kv(2);
+        // the wave's queries (+ bias) as fp16, 8 consecutive head dims per register quad; dialogs 0, 1 go to LDS now, 2, 3 wait in
+        // registers (48 instead of the accumulators' 96) until phase 3
+        uint4 qp[4][3];
+        {
+            float amax = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int nl = wn * 96 + 32 * k + 8 * lg;
+                    const float4 c0 = *reinterpret_cast<const float4*>(bias_lds + nl), c1 = *reinterpret_cast<const float4*>(bias_lds + nl + 4);
+                    const float v[8] = {acc[2 * k][mi][0] + c0.x, acc[2 * k][mi][1] + c0.y, acc[2 * k][mi][2] + c0.z, acc[2 * k][mi][3] + c0.w,
+                                        acc[2 * k + 1][mi][0] + c1.x, acc[2 * k + 1][mi][1] + c1.y, acc[2 * k + 1][mi][2] + c1.z, acc[2 * k + 1][mi][3] + c1.w};
+                    amax = amax2(amax2(amax2(amax2(amax, v[0], v[1]), v[2], v[3]), v[4], v[5]), v[6], v[7]);
+                    const uint2 h0 = pack4_hi_dither(v, dq), h1 = pack4_hi_dither(v + 4, dq);
+                    qp[mi][k] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                }
+            raise_fault(p.fault, amax > DIDI_F16_MAX, DIDI_FAULT_FP16_RANGE);
+        }
+        auto dump_q = [&]() {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int nl = wn * 96 + 32 * k + 8 * lg;
+                    *reinterpret_cast<uint4*>(Qimg + (((wm & 1) * 3 + (nl >> 6)) * 64) * 128 + img64(mi * 16 + lr, (nl & 63) >> 3)) = qp[mi][k];
+                }
+        };
+        if (wm < 2) dump_q();
+        const int trow = 4 * lg + (lr >> 2), tsub = 8 * (lr & 1);
+        const int d2 = wave >> 2, qb = wave & 3;  // this wave's dialog within the phase's pair, and its query block
+        const int q = qb * 16 + lr;
+#ifdef DIDI_STAMPS
+        unsigned long long xt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // kept in registers, written at the end: a stamp's store would count in vmcnt
+        xt[6] = __builtin_amdgcn_s_memtime();
+#endif
+        uint2 outv[4];
+        u16* optr = nullptr;  // where the previous phase's outputs go (lane's row and head; null: dialog past the batch)
+        int s_prev = 0, s_prev2 = 0, n_next = n2;  // stores of phase ph - 1 / ph - 2, K / V pieces of phase ph + 1 (this wave's)
+        for (int ph = 0; ph < 6; ++ph) {
+            const int hf = ph >= 3, hh = ph - 3 * hf;
+            if (ph == 3) {  // second pair of dialogs: its queries replace the first pair's once every wave is done with them
+                __builtin_amdgcn_s_barrier();
+                if (wm >= 2) dump_q();
+            }
+            // this wave's K / V pieces of phase ph have landed once everything issued after them is all that is in flight:
+            // the stores of phase ph - 2's outputs and the pieces of phase ph + 1
+            xa_wait_vm(ph == 0 ? n1 + n2 : s_prev2 + n_next);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // ... and every other wave's: phase ph's K / V, the Q images, the key bias are visible
+#ifdef DIDI_STAMPS
+            xt[ph] = __builtin_amdgcn_s_memtime();
+#endif
+            if (ph > 0) {
+                if (optr) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<uint2*>(optr + dt * 16) = outv[dt];
+                }
+                s_prev2 = s_prev;
+                n_next = ph + 2 < 6 ? xa_issue_kv(ph + 2) : 0;  // into the buffer phase ph - 1 read
+            } else {
+                n_next = n2;
+            }
+            const int d4 = hf * 2 + d2;
+            const int nkt = d4 == 0 ? xa_nkt[0] : d4 == 1 ? xa_nkt[1] : d4 == 2 ? xa_nkt[2] : xa_nkt[3];  // wave-uniform
+            const int nks = (nkt + 1) >> 1;
+            const char* Qs = Qimg + ((d2 * 3 + hh) * 64) * 128;
+            const char* Ks = smem + xa_buf(ph % 3) + d2 * 16384;
+            const char* Vs = Ks + 8192;
+            const float* mbd = mb + d4 * 64;
+            const bf16x8 qh0 = *reinterpret_cast<const bf16x8*>(Qs + img64(q, lg));
+            const bf16x8 qh1 = *reinterpret_cast<const bf16x8*>(Qs + img64(q, 4 + lg));
+            float sc[4][4];
+            float rmax = NEG, rsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt < nkt) {
+                    f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+                    s4 = mma16<true>(*reinterpret_cast<const bf16x8*>(Ks + img64(kt * 16 + lr, lg)), qh0, s4);
+                    s4 = mma16<true>(*reinterpret_cast<const bf16x8*>(Ks + img64(kt * 16 + lr, 4 + lg)), qh1, s4);
+                    const float4 m4 = *reinterpret_cast<const float4*>(mbd + kt * 16 + lg * 4);
+                    sc[kt][0] = fmaf(s4[0], p.attn_scale, m4.x);
+                    sc[kt][1] = fmaf(s4[1], p.attn_scale, m4.y);
+                    sc[kt][2] = fmaf(s4[2], p.attn_scale, m4.z);
+                    sc[kt][3] = fmaf(s4[3], p.attn_scale, m4.w);
+                    rmax = fmaxf(rmax, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[kt][r] = -INFINITY;
+                }
+            }
+            rmax = fmaxf(rmax, __shfl_xor(rmax, 16, 64));
+            rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+            v8s_ ph8[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                ph8[s] = v8s_{0, 0, 0, 0, 0, 0, 0, 0};
+                if (s < nks) {
+                    float pr[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        pr[e] = __builtin_amdgcn_exp2f(sc[2 * s + (e >> 2)][e & 3] - rmax);
+                        rsum += pr[e];
+                    }
+                    if (dith) {
+                        const uint2 a0 = pack4_hi_dither(pr, dith), a1 = pack4_hi_dither(pr + 4, dith);
+                        ph8[s] = __builtin_bit_cast(v8s_, make_uint4(a0.x, a0.y, a1.x, a1.y));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ph8[s][e] = (short)f16_bits(pr[e]);
+                    }
+                }
+            }
+            rsum += __shfl_xor(rsum, 16, 64);
+            rsum += __shfl_xor(rsum, 32, 64);
+            const float rinv = 1.0f / rsum;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o4 = {0.f, 0.f, 0.f, 0.f};
+                const int cch = 2 * dt + ((lr & 3) >> 1);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (s < nks) {
+                        const bf16x8 vh = lds_tr8(Vs + img64(32 * s + trow, cch) + tsub, Vs + img64(32 * s + 16 + trow, cch) + tsub);
+                        o4 = mma16<true>(vh, __builtin_bit_cast(bf16x8, ph8[s]), o4);
+                    }
+                }
+                float o[4] = {o4[0] * rinv, o4[1] * rinv, o4[2] * rinv, o4[3] * rinv};
+                asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));  // product, THEN conversion (see the self-attention form)
+                outv[dt] = dith ? pack4_hi_dither(o, dith) : pack4_hi(o, 1);
+            }
+            const bool in_batch = m0 + d4 * 64 < p.M;  // wave-uniform (M % 64 == 0)
+            optr = in_batch ? p.C_hi + (size_t)(m0 + d4 * 64 + q) * p.ldc + (3 * tn + hh) * 64 + lg * 4 : nullptr;
+            s_prev = in_batch ? 4 : 0;
+#ifdef DIDI_STAMPS
+            if (ph == 0) xt[7] = __builtin_amdgcn_s_memtime();
+            if (ph == 5) xt[8] = __builtin_amdgcn_s_memtime();
+#endif
+        }
+        if (optr) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<uint2*>(optr + dt * 16) = outv[dt];
+        }
+#ifdef DIDI_STAMPS
+        // slots: 3 queries converted (before phase 0's wait), 8 + ph after phase ph's barrier, 4 / 5 end of phase 0's / 5's arithmetic
+        if (p.stamps && lane == 0 && (wave & 3) == 0) {
+            unsigned long long* s_ = p.stamps + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 16;
+            s_[3] = xt[6]; s_[4] = xt[7]; s_[5] = xt[8];
+            for (int i = 0; i < 6; ++i) s_[8 + i] = xt[i];
+        }
+#endif
+        PP_STAMP(6);
+#ifdef DIDI_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        PP_STAMP(7);
+        return;
+    }
+    if constexpr (ATTN == 1) {
         constexpr float NEG = -3.4028234663852886e38f;
         f16_saturate_mode();
         const int dith = NPASS == 1 ? p.dither : 0;
@@ -1126,7 +1383,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                     const int m = min(m0 + wm * 64 + (half * 2 + mj) * 16 + lr, p.M - 1);
                     const int n = n0 + wn * 96 + 32 * k + 8 * lg;
                     rh[mj][k] = *reinterpret_cast<const uint4*>(p.R_hi + (size_t)m * p.ldr + n);
-                    rl[mj][k] = *reinterpret_cast<const uint4*>(p.R_lo + (size_t)m * p.ldr + n);
+                    rl[mj][k] = uint4{0, 0, 0, 0};
+                    if (p.R_lo) rl[mj][k] = *reinterpret_cast<const uint4*>(p.R_lo + (size_t)m * p.ldr + n);  // null: the residual is its hi plane
                 }
 #pragma unroll
             for (int mj = 0; mj < 2; ++mj) {
@@ -1262,6 +1520,12 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                 uint2 h0, l0, h1, l1;
                 if constexpr (F16) {  // packed truncating conversions (f16x2_dither), the offset that rounds to nearest when no dither is asked for
                     const int d = dith ? dith : DIDI_RNE_AS_DITHER;
+                    if (!p.C_lo) {  // hi plane only (the residual stream of a one-product call, DIDI_OPT_HI_RESIDUAL)
+                        h0 = pack4_hi_dither(y, d);
+                        h1 = pack4_hi_dither(y + 4, d);
+                        *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                        continue;
+                    }
                     split4_dither(y, h0, l0, d);
                     split4_dither(y + 4, h1, l1, d);
                 } else {
@@ -1269,7 +1533,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                     split4(y + 4, h1, l1, 0);
                 }
                 *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-                *reinterpret_cast<uint4*>(p.C_lo + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                if (p.C_lo) *reinterpret_cast<uint4*>(p.C_lo + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
             }
         }
         PP_STAMP(6);  // every store issued
@@ -1331,10 +1595,10 @@ static bool gemm_pp_enabled() { return didi_opt(DIDI_OPT_GEMM_PP) != 0; }
 // Per-device set-up, done on the first call on each device: the > 64 KiB dynamic-LDS opt-ins of every big-tile kernel
 // (function attributes live per device) and the device's CU count.  Keyed by the CURRENT device, so a process that
 // drives several GPUs gets each one's own values.
-template <int NPASS, bool F16, bool LN, bool AMAX, bool ATTN = false>
+template <int NPASS, bool F16, bool LN, bool AMAX, int ATTN = 0>
 static bool opt_in_pp() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<NPASS, F16, LN, AMAX, ATTN>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) == hipSuccess;
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ATTN == 2 ? XA_LDS_BYTES : PP_LDS_BYTES) == hipSuccess;
 }
 struct DeviceInfo { int state; int ncu; };  // state: 0 = not probed, 1 = ready, -1 = failed
 static const DeviceInfo* device_info() {
@@ -1353,7 +1617,8 @@ static const DeviceInfo* device_info() {
         ok = ok && opt_in_pp<3, false, false, true>() && opt_in_pp<1, false, false, true>() && opt_in_pp<1, true, false, true>();
         ok = ok && opt_in_pp<2, true, false, false>() && opt_in_pp<2, true, true, false>() && opt_in_pp<2, true, false, true>();
         ok = ok && opt_in_pp<3, true, false, false>() && opt_in_pp<3, true, false, true>() && opt_in_pp<3, true, true, false>();
-        ok = ok && opt_in_pp<1, true, false, false, true>() && opt_in_pp<2, true, false, false, true>();
+        ok = ok && opt_in_pp<1, true, false, false, 1>() && opt_in_pp<2, true, false, false, 1>();
+        ok = ok && opt_in_pp<1, true, false, false, 2>() && opt_in_pp<2, true, false, false, 2>();
         int c = 0;
         ok = ok && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0;
         d.ncu = c;
@@ -1471,8 +1736,47 @@ extern "C" int didi_qkv_self_attention(const didi_gemm_args* a, int heads, int S
     p.tiles_m = cdiv(p.M, 256); p.tiles_n = heads;
     const int grid = p.tiles_m * p.tiles_n;
     hipStream_t st = as_stream(stream);
-    if (p.npass == 2) gemm_pp_kernel<2, true, false, false, true><<<grid, 512, PP_LDS_BYTES, st>>>(p);
-    else gemm_pp_kernel<1, true, false, false, true><<<grid, 512, PP_LDS_BYTES, st>>>(p);
+    if (p.npass == 2) gemm_pp_kernel<2, true, false, false, 1><<<grid, 512, PP_LDS_BYTES, st>>>(p);
+    else gemm_pp_kernel<1, true, false, false, 1><<<grid, 512, PP_LDS_BYTES, st>>>(p);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ cross-attention query projection + cross-attention
+extern "C" int didi_q_cross_attention_supported(int M, int H, int heads, int S, int C, int K, int precision) {
+    return (precision == DIDI_PREC_FP16 || precision == DIDI_PREC_FP16X2) && S == 64 && C == 64 && heads > 0 && heads % 3 == 0 &&
+           H == heads * 64 && M >= 2048 && M % 64 == 0 && K % 64 == 0 && K >= 128;
+}
+
+extern "C" int didi_q_cross_attention(const didi_gemm_args* a, const uint16_t* K_hi, const uint16_t* V_hi, int ldkv, const int32_t* key_mask,
+                                      const int32_t* key_count, int heads, int S, int C, float scale, void* stream) {
+    DIDI_CHECK_ARG(a && a->A_hi && a->W_hi && a->bias && a->C_hi && K_hi && V_hi && a->M >= 0 && a->N > 0 && a->K > 0 && scale >= 0.f);
+    DIDI_CHECK_ARG(a->act == DIDI_ACT_NONE && !a->C_f32 && !a->C_lo && !a->R_f32 && !a->R_hi && !a->R_lo);
+    if (!didi_q_cross_attention_supported(a->M, a->N, heads, S, C, a->K, a->precision)) return DIDI_ERR_UNSUPPORTED;
+    DIDI_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K && a->ldc % 4 == 0 && a->ldc >= a->N);
+    DIDI_CHECK_ARG(ldkv % 8 == 0 && ldkv >= a->N && al16(K_hi) && al16(V_hi));
+    DIDI_CHECK_ARG(al16(a->A_hi) && al16(a->W_hi) && al16(a->W_lo) && al16(a->bias) && al8(a->C_hi));
+    DIDI_CHECK_ARG(a->act_dither >= 0 && a->act_dither < 8192);
+    if (a->M == 0) return DIDI_OK;
+    if (!allow_big_lds()) return DIDI_ERR_LAUNCH;
+    GemmParams p{};
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    int rc = fill_operands(p, a->precision, a->A_hi, a->A_lo, a->W_hi, a->W_lo);
+    if (rc != DIDI_OK) return rc;
+    p.lda = a->lda; p.ldw = a->ldw; p.bias = a->bias; p.act = DIDI_ACT_NONE;
+    p.C_hi = a->C_hi; p.ldc = a->ldc; p.fault = a->fault; p.dither = a->act_dither;
+    p.attn_K = K_hi; p.attn_V = V_hi; p.attn_ldkv = ldkv; p.attn_B = a->M / 64;
+    p.attn_mask = key_mask; p.attn_count = key_mask ? key_count : nullptr;
+    p.attn_scale = 1.4426950408889634f * (scale > 0.f ? scale : 0.125f);
+    p.attn_mask0 = 0.0f;
+#ifdef DIDI_STAMPS
+    p.stamps = g_stamp_buf;
+#endif
+    p.tiles_m = cdiv(p.M, 256); p.tiles_n = a->N / BBN;
+    const int grid = p.tiles_m * p.tiles_n;
+    hipStream_t st = as_stream(stream);
+    if (p.npass == 2) gemm_pp_kernel<2, true, false, false, 2><<<grid, 512, XA_LDS_BYTES, st>>>(p);
+    else gemm_pp_kernel<1, true, false, false, 2><<<grid, 512, XA_LDS_BYTES, st>>>(p);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }
@@ -1673,8 +1977,8 @@ extern "C" size_t didi_gemm_ln_stats_bytes(int M) { return (size_t)cdiv(M, 256) 
 
 extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, uint16_t* y_hi,
                             uint16_t* y_lo, float* y_f32, void* stats, uint32_t epoch, void* stream) {
-    DIDI_CHECK_ARG(a && a->A_hi && a->W_hi && a->bias && gamma && beta && y_hi && y_lo && stats && a->M >= 0);
-    DIDI_CHECK_ARG(a->act == DIDI_ACT_NONE && !a->C_f32 && !a->C_hi && !a->C_lo && a->R_hi && a->R_lo && !a->R_f32);
+    DIDI_CHECK_ARG(a && a->A_hi && a->W_hi && a->bias && gamma && beta && y_hi && stats && a->M >= 0);
+    DIDI_CHECK_ARG(a->act == DIDI_ACT_NONE && !a->C_f32 && !a->C_hi && !a->C_lo && a->R_hi && !a->R_f32);
     if (!didi_gemm_ln_supported(a->M, a->N, a->K, a->precision)) return DIDI_ERR_UNSUPPORTED;
     DIDI_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K && a->ldr % 8 == 0 && a->ldr >= a->N);
     DIDI_CHECK_ARG(al16(a->A_hi) && al16(a->A_lo) && al16(a->W_hi) && al16(a->W_lo) && al16(a->bias) && al16(a->R_hi) && al16(a->R_lo));
@@ -1710,8 +2014,8 @@ extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const f
         p.M = (int)std::min<size_t>((size_t)nb * 256, (size_t)a->M - r0);
         p.tiles_m = nb;
         p.A_hi = a->A_hi + r0 * a->lda; p.A_lo = (p.npass == 3 ? a->A_lo : a->A_hi) + r0 * a->lda;
-        p.R_hi = a->R_hi + r0 * a->ldr; p.R_lo = a->R_lo + r0 * a->ldr;
-        p.C_hi = y_hi + r0 * a->N; p.C_lo = y_lo + r0 * a->N; p.C_f32 = y_f32 ? y_f32 + r0 * a->N : nullptr;
+        p.R_hi = a->R_hi + r0 * a->ldr; p.R_lo = a->R_lo ? a->R_lo + r0 * a->ldr : nullptr;
+        p.C_hi = y_hi + r0 * a->N; p.C_lo = y_lo ? y_lo + r0 * a->N : nullptr; p.C_f32 = y_f32 ? y_f32 + r0 * a->N : nullptr;
         p.ln_stats = reinterpret_cast<unsigned long long*>(stats) + (size_t)b0 * 4 * 512;
         const int grid = nb * 4;
         if (p.npass == 3 && p.f16) gemm_pp_kernel<3, true, true><<<grid, 512, lds, st>>>(p);

@@ -74,9 +74,14 @@ enum {
     DIDI_OPT_X2_GEMMS = 7,     /* bit mask of the decoder GEMMs that multiply the weights' remainder plane in an FP16X2 call: bit 0 qkv,
                                   1 attention output, 2 cross-attention query, 3 cross-attention output, 4 FFN up, 5 FFN down; the others
                                   run one product there.  Default 63 (all) */
-    DIDI_OPT_FUSED_ATTN = 8,   /* 1 (default): the engine runs a layer's query/key/value projections and its causal self-attention as ONE
-                                  launch where didi_qkv_self_attention supports the shape; 0: didi_gemm + didi_attention */
-    DIDI_OPT_COUNT = 9
+    DIDI_OPT_FUSED_ATTN = 8,   /* bit 0: the engine runs a layer's query/key/value projections and its causal self-attention as ONE launch
+                                  where didi_qkv_self_attention supports the shape; bit 1: its cross-attention query projection and
+                                  cross-attention as one where didi_q_cross_attention does; a clear bit: didi_gemm + didi_attention.
+                                  Default 3 */
+    DIDI_OPT_HI_RESIDUAL = 9,  /* 1: in DIDI_PREC_FP16 (one-product) decoder calls the residual stream between the fused projection +
+                                  LayerNorm launches travels as its fp16 hi plane alone (12 bits; the remainder plane is neither written
+                                  nor re-joined): half the bytes of those launches' epilogues.  0 (default): hi + lo everywhere */
+    DIDI_OPT_COUNT = 10
 };
 int didi_set_option(int key, int value);
 int didi_get_option(int key, int* value);
@@ -260,6 +265,24 @@ int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const float* beta,
  * K % 64 == 0; otherwise DIDI_ERR_UNSUPPORTED and the caller runs the two launches. */
 int didi_qkv_self_attention_supported(int M, int H, int heads, int S, int K, int precision);
 int didi_qkv_self_attention(const didi_gemm_args* a, int heads, int S, float scale, void* stream);
+
+/* BertCrossAttention in ONE launch (HF:models/bert/modeling_bert.py:230-279: the `query` Linear :253, then
+ * eager_attention_forward :111-136 over the encoder's keys and values with the additive padding mask of the context,
+ * src/diffusion/model.py:193-197 `encoder_attention_mask`), the keys and values being the hoisted per-layer cache of
+ * didi_decoder_prepare_context (they do not depend on the denoiser's input):
+ *   O[b, q, head] = softmax(Q K_b^T / sqrt(64) + mask_b) V_b,   Q = A W^T + bias
+ * for dialogs of exactly S = 64 target positions, C = 64 context positions and 64-wide heads, heads % 3 == 0.  `a` is the
+ * didi_gemm_args of the query projection (W [H, K], bias [H], DIDI_PREC_FP16 or DIDI_PREC_FP16X2, C_hi = O [M, ldc >= H] fp16
+ * plane, nothing else set).  K_hi / V_hi: fp16 planes [B * 64][ldkv], head h at columns h * 64 ..; key_mask [B][64] int32
+ * (0 = padded key) or NULL; key_count [B] (didi_key_counts: contexts are right-padded, keys from the count on are neither
+ * loaded nor multiplied) or NULL.  A 256-row tile band is four whole dialogs and a 192-column tile the queries of three
+ * heads: the workgroup that holds the tile's accumulators streams the K / V of (dialog, head) through LDS under the
+ * arithmetic.  Same results, bit for bit, as didi_gemm followed by didi_attention(key_mask, key_count) -- minus the query
+ * plane's round trip and one launch.  didi_q_cross_attention_supported: S == C == 64, H == 64 * heads, heads % 3 == 0,
+ * M >= 2048, M % 64 == 0, K % 64 == 0; otherwise DIDI_ERR_UNSUPPORTED and the caller runs the two launches. */
+int didi_q_cross_attention_supported(int M, int H, int heads, int S, int C, int K, int precision);
+int didi_q_cross_attention(const didi_gemm_args* a, const uint16_t* K_hi, const uint16_t* V_hi, int ldkv, const int32_t* key_mask,
+                           const int32_t* key_count, int heads, int S, int C, float scale, void* stream);
 
 /* Small batches (M < 2048 rows: interactive use, a handful of dialogs).  The same arithmetic as didi_gemm (+ an
  * optional LayerNorm over the N output columns: gamma/beta non-NULL, as didi_gemm_ln), organised for latency: K is split

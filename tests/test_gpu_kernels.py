@@ -685,3 +685,73 @@ def test_qkv_self_attention_fused_equals_the_two_launches(ops, B, precision):
     assert not _lib.lib.didi_qkv_self_attention_supported(M, H, heads, 63, H, g.precision)
     assert not _lib.lib.didi_qkv_self_attention_supported(M, H, heads, S, H, ops.PRECISIONS["bf16x3"])
     assert not _lib.lib.didi_qkv_self_attention_supported(1024, H, heads, S, H, g.precision)
+
+
+@pytest.mark.parametrize("precision", ["fp16", "fp16x2"])
+@pytest.mark.parametrize("B", [32, 33, 41])
+def test_q_cross_attention_fused_equals_the_two_launches(ops, B, precision):
+    """didi_q_cross_attention (cross-attention query projection + attention over the hoisted keys / values in one launch,
+    S = C = 64, 64-wide heads) against didi_gemm followed by didi_attention(key_mask, key_count): bit-identical outputs for whole
+    row bands (B = 32) and ragged last bands (33, 41 dialogs), with right-padded contexts of every length class (1 key, a
+    partial 16-key tile, exactly 32, 63, all 64, and the nothing-visible corner), with and without key counts, with and
+    without the activation dither; and against an fp64 reference of the attention on the rounded queries."""
+    import ctypes as C
+
+    from didi_amd import _lib
+
+    heads, S, Cn, H = 12, 64, 64, 768
+    M = B * S
+    x = rnd(M, H, seed=81)
+    w, bias = rnd(H, H, seed=82, scale=0.05), rnd(H, seed=83, scale=0.5)
+    kv = rnd(B * Cn, 2 * H, seed=84)
+    x_hi, x_lo = ops.split(x.cuda(), dtype=torch.float16)
+    w_hi, w_lo = ops.split(w.cuda(), dtype=torch.float16)
+    kv_hi = kv.cuda().to(torch.float16)
+    lens = torch.tensor([1, 5, 16, 17, 31, 32, 33, 48, 63, 64, 0, 24], dtype=torch.int64).repeat((B + 11) // 12)[:B]
+    mask = (torch.arange(Cn)[None, :] < lens[:, None]).to(torch.int32)
+    mask[3, 2] = 0  # a hole inside the visible prefix: the mask, not the count, hides it
+    mask_dev = mask.cuda()
+    counts = torch.empty(B, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib.didi_key_counts(mask_dev.data_ptr(), B, Cn, counts.data_ptr(), _lib.current_stream()), "key_counts")
+    b_dev = bias.cuda()
+    for dither, use_counts in ((0, True), (3072, True), (0, False)):
+        g = _lib.GemmArgs()
+        g.M, g.N, g.K, g.precision = M, H, H, ops.PRECISIONS[precision]
+        g.A_hi, g.A_lo, g.lda = x_hi.data_ptr(), x_lo.data_ptr(), H
+        g.W_hi, g.W_lo, g.ldw = w_hi.data_ptr(), w_lo.data_ptr(), H
+        g.bias, g.act, g.act_dither = b_dev.data_ptr(), _lib.ACT_NONE, dither if precision == "fp16" else 0
+        cnt_ptr = counts.data_ptr() if use_counts else None
+        # the two launches
+        q = torch.empty((M, H), dtype=torch.float16, device="cuda")
+        g.C_hi, g.ldc = q.data_ptr(), H
+        _lib.check(_lib.lib.didi_gemm(C.byref(g), _lib.current_stream()), "gemm")
+        want = torch.empty((M, H), dtype=torch.float16, device="cuda")
+        a = _lib.AttnArgs()
+        a.B, a.heads, a.Sq, a.Sk, a.D = B, heads, S, Cn, 64
+        a.precision, a.causal, a.act_dither = ops.PRECISIONS["fp16"], 0, g.act_dither
+        a.Q_hi, a.ldq = q.data_ptr(), H
+        a.K_hi, a.ldk, a.V_hi, a.ldv = kv_hi.data_ptr(), 2 * H, kv_hi.data_ptr() + 2 * H, 2 * H
+        a.key_mask, a.key_count = mask_dev.data_ptr(), cnt_ptr
+        a.O_hi, a.ldo = want.data_ptr(), H
+        _lib.check(_lib.lib.didi_attention(C.byref(a), _lib.current_stream()), "attention")
+        # one launch
+        got = torch.full((M, H), float("nan"), dtype=torch.float16, device="cuda")
+        g.C_hi, g.ldc = got.data_ptr(), H
+        assert _lib.lib.didi_q_cross_attention_supported(M, H, heads, S, Cn, H, g.precision)
+        _lib.check(_lib.lib.didi_q_cross_attention(C.byref(g), kv_hi.data_ptr(), kv_hi.data_ptr() + 2 * H, 2 * H, mask_dev.data_ptr(), cnt_ptr,
+                                                    heads, S, Cn, 0.0, _lib.current_stream()), "q_cross_attention")
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (f"B={B} {precision} dither={dither} counts={use_counts}: "
+                                        f"{(got.float() - want.float()).abs().max().item()} at rows "
+                                        f"{(got != want).any(1).nonzero().flatten()[:8].tolist()}")
+    # fp64 attention on the rounded queries of the last (undithered) run; the nothing-visible dialogs attend uniformly
+    qd = q.double().cpu().view(B, S, heads, 64).transpose(1, 2)
+    kd, vd = (kv_hi[:, i * H:(i + 1) * H].double().cpu().view(B, Cn, heads, 64).transpose(1, 2) for i in range(2))
+    sc = qd @ kd.transpose(-1, -2) / 8.0 + (1.0 - mask[:, None, None, :].double()) * torch.finfo(torch.float32).min
+    ref = (sc.float().double().softmax(-1) @ vd).transpose(1, 2).reshape(M, H)
+    assert rel_l2(want, ref) <= 1e-3
+    # shapes the fused form does not take
+    assert not _lib.lib.didi_q_cross_attention_supported(M, H, heads, S, 63, H, g.precision)
+    assert not _lib.lib.didi_q_cross_attention_supported(M, 512, 8, S, Cn, 512, g.precision)
+    assert not _lib.lib.didi_q_cross_attention_supported(M, H, heads, S, Cn, H, ops.PRECISIONS["fp16x3"])
+    assert not _lib.lib.didi_q_cross_attention_supported(1024, H, heads, S, Cn, H, g.precision)

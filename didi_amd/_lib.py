@@ -26,7 +26,7 @@ ERR_FAULT = -5
 FAULT_LN_EXCHANGE, FAULT_FP16_RANGE = 1, 2
 ABI_VERSION = 5
 # didi_set_option keys (tuning switches for A/B runs; defaults = production path)
-OPTIONS = {"GEMM_LN": 0, "GEMM_SMALL": 1, "GEMM_BIG": 2, "GEMM_PP": 3, "GEMM_MT": 4, "BIG_MIN_M": 5, "SMALL_MAX_M": 6, "X2_GEMMS": 7, "FUSED_ATTN": 8, "HI_RESIDUAL": 9}
+OPTIONS = {"GEMM_LN": 0, "GEMM_SMALL": 1, "GEMM_BIG": 2, "GEMM_PP": 3, "GEMM_MT": 4, "BIG_MIN_M": 5, "SMALL_MAX_M": 6, "X2_GEMMS": 7, "FUSED_ATTN": 8, "HI_RESIDUAL": 9, "LO8_RESIDUAL": 10}
 
 
 class StepArgs(C.Structure):
@@ -145,6 +145,8 @@ SYMBOLS = [
     ("didi_gemm_ln_stats_bytes", C.c_size_t, [C.c_int]),
     ("didi_gemm_ln", C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("didi_gemm_ln_lo8", C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
     ("didi_qkv_self_attention_supported", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("didi_qkv_self_attention", C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_int, C.c_float, C.c_void_p]),
     ("didi_q_cross_attention_supported", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -82,6 +82,26 @@ __device__ __forceinline__ void split4_dither(const float v[4], uint2& hi, uint2
     lo = pack4_hi_dither(r, DIDI_RNE_AS_DITHER);
 }
 
+// The remainder plane as BYTES ("lo8"): byte = top byte (e5m2) of fp16(256 * (v - hi)), rounded half away from zero.  hi + lo8
+// carries 14 bits and more (absolute error <= 2^-25 below |v| = 2^-10): what the residual stream of a one- or two-product call
+// needs -- no GEMM of such a call multiplies an activation's remainder, it is only re-joined by the next residual add -- at 3
+// instead of 4 bytes per value and direction in the launches whose epilogues are bound by exactly those bytes.  The factor 256
+// keeps the remainders of small values out of fp16's subnormal range.
+#define DIDI_LO8_SCALE 256.0f
+__device__ __forceinline__ void split4_dither_lo8(const float v[4], uint2& hi, uint32_t& lo8, int d) {
+    hi = pack4_hi_dither(v, d);
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = __builtin_bit_cast(h2, hi.x), b = __builtin_bit_cast(h2, hi.y);
+    const float r[4] = {(v[0] - (float)a[0]) * DIDI_LO8_SCALE, (v[1] - (float)a[1]) * DIDI_LO8_SCALE, (v[2] - (float)b[0]) * DIDI_LO8_SCALE,
+                        (v[3] - (float)b[1]) * DIDI_LO8_SCALE};
+    const uint2 l = pack4_hi_dither(r, DIDI_RNE_AS_DITHER);
+    lo8 = __builtin_amdgcn_perm(l.y + 0x00800080u, l.x + 0x00800080u, 0x07050301u);  // bytes 1 and 3 of both words
+}
+// four lo8 bytes -> four fp16 bit patterns (values 256 x the remainders)
+__device__ __forceinline__ uint2 lo8_unpack4(uint32_t w) {
+    return make_uint2(__builtin_amdgcn_perm(0u, w, 0x010c000cu), __builtin_amdgcn_perm(0u, w, 0x030c020cu));
+}
+
 // 4 consecutive values -> two 8-byte packs (hi plane, lo plane)
 __device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo, int f16 = 0) {
     u16 h[4], l[4];

@@ -102,9 +102,11 @@ static bool gemm_ln_fuses(const didi_linear& w, int precision, int M) {
 // else GEMM -> fp32 tmp -> LayerNorm.  `epoch` tags this launch's statistics in the shared `stats` buffer.
 int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi, const u16* a_lo, int lda, const u16* r_hi,
             const u16* r_lo, int ldr, float* tmp, void* stats, uint32_t epoch, const float* gamma, const float* beta, float eps,
-            u16* y_hi, u16* y_lo, float* y_f32, void* stream, Prof* prof, void* small_ws, uint32_t* fault, int dither = 0, int hi_only = 0) {  // hi_only: bit 0 the residual, bit 1 the output
+            u16* y_hi, u16* y_lo, float* y_f32, void* stream, Prof* prof, void* small_ws, uint32_t* fault, int dither = 0, int hi_only = 0, int lo_bytes = 0) {
+    // hi_only: bit 0: the residual is its hi plane, bit 1: no remainder plane is written; lo_bytes: bit 0: r_lo is a byte plane
+    // (split4_dither_lo8), bit 1: y_lo is written as one.  Both only where the fused launch takes the shape (the caller checked).
     const bool fuse = didi_opt(DIDI_OPT_GEMM_LN) != 0;  // 0: A/B switch back to GEMM + LayerNorm
-    if (hi_only && !gemm_ln_fuses(w, precision, M)) return DIDI_ERR_UNSUPPORTED;  // the caller checked: the other forms read r_lo
+    if ((hi_only || lo_bytes) && !gemm_ln_fuses(w, precision, M)) return DIDI_ERR_UNSUPPORTED;  // the other forms read / write 16-bit r_lo, y_lo
     if (fuse && didi_gemm_ln_supported(M, w.N, w.K, precision) && w.bias) {
         didi_gemm_args g{};
         g.fault = fault;
@@ -115,7 +117,7 @@ int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi
         g.bias = w.bias; g.act = DIDI_ACT_NONE;
         g.R_hi = r_hi; g.R_lo = (hi_only & 1) ? nullptr : r_lo; g.ldr = ldr;
         if (prof) prof->mark(stream);
-        const int rc = didi_gemm_ln(&g, gamma, beta, eps, y_hi, (hi_only & 2) ? nullptr : y_lo, y_f32, stats, epoch, stream);
+        const int rc = didi_gemm_ln_lo8(&g, gamma, beta, eps, y_hi, (hi_only & 2) ? nullptr : y_lo, y_f32, stats, epoch, lo_bytes, stream);
         if (prof) prof->mark(stream);
         return rc;
     }
@@ -142,7 +144,7 @@ int gemm_ln(const didi_linear& w, int precision, int fmt, int M, const u16* a_hi
 
 // ------------------------------------------------------------------ tuning switches (didi_set_option)
 static int g_options[DIDI_OPT_COUNT] = {/*GEMM_LN*/ 1, /*GEMM_SMALL*/ 1, /*GEMM_BIG*/ 1, /*GEMM_PP*/ 1, /*GEMM_MT*/ 4,
-                                        /*BIG_MIN_M*/ 2048, /*SMALL_MAX_M*/ 2048, /*X2_GEMMS*/ 63, /*FUSED_ATTN*/ 3, /*HI_RESIDUAL*/ 0};
+                                        /*BIG_MIN_M*/ 2048, /*SMALL_MAX_M*/ 2048, /*X2_GEMMS*/ 63, /*FUSED_ATTN*/ 3, /*HI_RESIDUAL*/ 0, /*LO8_RESIDUAL*/ 1};
 int didi_opt(int key) { return g_options[key]; }
 extern "C" int didi_set_option(int key, int value) {
     DIDI_CHECK_ARG(key >= 0 && key < DIDI_OPT_COUNT);
@@ -252,6 +254,17 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
         hi_res = gemm_ln_fuses(ly.attn_out, prec, M) && gemm_ln_fuses(ly.cross_out, prec, M) && gemm_ln_fuses(ly.ffn_down, prec, M);
     }
 
+    // one- and two-product fp16 calls (DIDI_OPT_LO8_RESIDUAL): no GEMM of such a call multiplies an activation's remainder, the
+    // residual add alone re-joins it -- so between the fused projection + LayerNorm launches the remainder plane of the residual
+    // stream travels as bytes (hi + lo8: 14 bits and more instead of 22; `tmp`, unused by those launches, holds them): 3 instead
+    // of 4 bytes per value and direction.  The first launch reads the step kernel's 16-bit plane, the last writes one.
+    bool lo8 = !hi_res && didi_opt(DIDI_OPT_LO8_RESIDUAL) != 0 && (prec == DIDI_PREC_FP16 || prec == DIDI_PREC_FP16X2);
+    for (int l = 0; l < dec->L && lo8; ++l) {
+        const didi_decoder_layer& ly = dec->layers_host[l];
+        lo8 = gemm_ln_fuses(ly.attn_out, pc(1), M) && gemm_ln_fuses(ly.cross_out, pc(3), M) && gemm_ln_fuses(ly.ffn_down, pc(5), M);
+    }
+    u16* const h_lo8 = reinterpret_cast<u16*>(w.tmp);
+
     for (int l = 0; l < dec->L; ++l) {
         const didi_decoder_layer& ly = dec->layers_host[l];
         const bool last = l == dec->L - 1;
@@ -288,8 +301,9 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
             at.V_hi = w.qkv_hi + 2 * H; at.V_lo = x3 ? w.qkv_lo + 2 * H : nullptr; at.ldv = 3 * H;
             TRY(didi_attention(&at, stream));
         }
-        TRY(gemm_ln(ly.attn_out, pc(1), fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln1_g, ly.ln1_b,
-                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault, dith, hi_res ? 3 : 0));
+        TRY(gemm_ln(ly.attn_out, pc(1), fmt, M, w.att_hi, w.att_lo, H, w.h_hi, lo8 && l > 0 ? h_lo8 : w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln1_g,
+                    ly.ln1_b, dec->ln_eps, w.h_hi, lo8 ? h_lo8 : w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault, dith, hi_res ? 3 : 0,
+                    lo8 ? (l > 0 ? 3 : 2) : 0));
         // --- cross-attention block (K/V hoisted: didi_decoder_prepare_context)
         u16* q_hi = w.qkv_hi;
         u16* q_lo = x3 ? w.qkv_lo : nullptr;
@@ -320,15 +334,16 @@ extern "C" int didi_decoder_forward(const didi_decoder* dec, const didi_forward_
             at.V_hi = a->kv_hi + kvoff + H; at.V_lo = x3 ? a->kv_lo + kvoff + H : nullptr; at.ldv = 2 * H;
             TRY(didi_attention(&at, stream));
         }
-        TRY(gemm_ln(ly.cross_out, pc(3), fmt, M, w.att_hi, w.att_lo, H, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln2_g, ly.ln2_b,
-                    dec->ln_eps, w.h_hi, w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault, dith, hi_res ? 3 : 0));
+        TRY(gemm_ln(ly.cross_out, pc(3), fmt, M, w.att_hi, w.att_lo, H, w.h_hi, lo8 ? h_lo8 : w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln2_g, ly.ln2_b,
+                    dec->ln_eps, w.h_hi, lo8 ? h_lo8 : w.h_lo, nullptr, stream, &prof, w.small_ws, a->fault, dith, hi_res ? 3 : 0, lo8 ? 3 : 0));
         // --- feed-forward block
         TRY(gemm(ly.ffn_up, pc(4), M, w.h_hi, w.h_lo, H, DIDI_ACT_GELU, nullptr, nullptr, 0, nullptr, w.ffn_hi,
                  ffn_lo ? w.ffn_lo : nullptr, I, stream, &prof, w.small_ws, a->fault, dith));
         u16* o_hi = last && a->x0_hi ? a->x0_hi : w.h_hi;
         u16* o_lo = last && a->x0_hi ? a->x0_lo : w.h_lo;
-        TRY(gemm_ln(ly.ffn_down, pc(5), fmt, M, w.ffn_hi, w.ffn_lo, I, w.h_hi, w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln3_g, ly.ln3_b,
-                    dec->ln_eps, o_hi, o_lo, last ? a->x0_f32 : nullptr, stream, &prof, w.small_ws, a->fault, dith, hi_res ? (last ? 1 : 3) : 0));
+        TRY(gemm_ln(ly.ffn_down, pc(5), fmt, M, w.ffn_hi, w.ffn_lo, I, w.h_hi, lo8 ? h_lo8 : w.h_lo, H, w.tmp, w.ln_stats, ++epoch, ly.ln3_g, ly.ln3_b,
+                    dec->ln_eps, o_hi, lo8 && !last ? h_lo8 : o_lo, last ? a->x0_f32 : nullptr, stream, &prof, w.small_ws, a->fault, dith,
+                    hi_res ? (last ? 1 : 3) : 0, lo8 ? (last ? 1 : 3) : 0));
     }
     if (a->prof_used_host) *a->prof_used_host = prof.used;
     return DIDI_OK;

@@ -77,6 +77,7 @@ struct GemmParams {
     const u16 *attn_K, *attn_V;    // ATTN == 2 (cross-attention): hoisted K / V planes [B * 64][attn_ldkv], head h at column h * 64
     int attn_ldkv, attn_B;
     const int32_t *attn_mask, *attn_count;  // [B][64] key mask (0 = padded) or null; [B] visible-key counts or null
+    int lo8;                       // LN form, fp16 planes: bit 0: R_lo is a BYTE plane (split4_dither_lo8), bit 1: C_lo is written as one
     float attn_scale;              // ATTN form: softmax scale * log2(e)
     float attn_mask0;              // ATTN form: the additive mask of a visible key, 0.0f, as a run-time value: the scores are then
                                    // fmaf(acc, scale, mask) exactly as in attn_kernel (a literal 0 would let the compiler fold the
@@ -1384,8 +1385,16 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                     const int n = n0 + wn * 96 + 32 * k + 8 * lg;
                     rh[mj][k] = *reinterpret_cast<const uint4*>(p.R_hi + (size_t)m * p.ldr + n);
                     rl[mj][k] = uint4{0, 0, 0, 0};
+                    if constexpr (F16) {
+                        if (p.lo8 & 1) {  // byte plane: 8 B per lane; the factor 1 / 256 rides in the add below
+                            const uint2 b8 = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.R_lo) + (size_t)m * p.ldr + n);
+                            rl[mj][k] = make_uint4(b8.x, b8.y, 0, 0);
+                            continue;
+                        }
+                    }
                     if (p.R_lo) rl[mj][k] = *reinterpret_cast<const uint4*>(p.R_lo + (size_t)m * p.ldr + n);  // null: the residual is its hi plane
                 }
+            const float rl_scale = F16 && (p.lo8 & 1) ? 1.0f / DIDI_LO8_SCALE : 1.0f;
 #pragma unroll
             for (int mj = 0; mj < 2; ++mj) {
                 const int mi = half * 2 + mj;
@@ -1397,12 +1406,17 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                     float rH[8], rL[8];
                     unpack4(make_uint2(rh[mj][k].x, rh[mj][k].y), rH, F16);  // the template's format: p.f16 would convert both ways
                     unpack4(make_uint2(rh[mj][k].z, rh[mj][k].w), rH + 4, F16);
-                    unpack4(make_uint2(rl[mj][k].x, rl[mj][k].y), rL, F16);
-                    unpack4(make_uint2(rl[mj][k].z, rl[mj][k].w), rL + 4, F16);
+                    if (F16 && (p.lo8 & 1)) {
+                        unpack4(lo8_unpack4(rl[mj][k].x), rL, 1);
+                        unpack4(lo8_unpack4(rl[mj][k].y), rL + 4, 1);
+                    } else {
+                        unpack4(make_uint2(rl[mj][k].x, rl[mj][k].y), rL, F16);
+                        unpack4(make_uint2(rl[mj][k].z, rl[mj][k].w), rL + 4, F16);
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        acc[2 * k][mi][i] = ((acc[2 * k][mi][i] + b[i]) + rH[i]) + rL[i];
-                        acc[2 * k + 1][mi][i] = ((acc[2 * k + 1][mi][i] + b[4 + i]) + rH[4 + i]) + rL[4 + i];
+                        acc[2 * k][mi][i] = fmaf(rL[i], rl_scale, (acc[2 * k][mi][i] + b[i]) + rH[i]);  // rl_scale = 1: the plain sum, bit for bit
+                        acc[2 * k + 1][mi][i] = fmaf(rL[4 + i], rl_scale, (acc[2 * k + 1][mi][i] + b[4 + i]) + rH[4 + i]);
                     }
                 }
             }
@@ -1524,6 +1538,14 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                         h0 = pack4_hi_dither(y, d);
                         h1 = pack4_hi_dither(y + 4, d);
                         *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                        continue;
+                    }
+                    if (p.lo8 & 2) {  // remainder plane as bytes
+                        uint32_t b0, b1;
+                        split4_dither_lo8(y, h0, b0, d);
+                        split4_dither_lo8(y + 4, h1, b1, d);
+                        *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(p.C_lo) + o) = make_uint2(b0, b1);
                         continue;
                     }
                     split4_dither(y, h0, l0, d);
@@ -1975,14 +1997,16 @@ extern "C" int didi_gemm_ln_supported(int M, int N, int K, int precision) {
 
 extern "C" size_t didi_gemm_ln_stats_bytes(int M) { return (size_t)cdiv(M, 256) * 4 * 256 * 2 * sizeof(unsigned long long); }
 
-extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, uint16_t* y_hi,
-                            uint16_t* y_lo, float* y_f32, void* stats, uint32_t epoch, void* stream) {
+static int gemm_ln_impl(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, uint16_t* y_hi,
+                        uint16_t* y_lo, float* y_f32, void* stats, uint32_t epoch, int lo_bytes, void* stream) {
     DIDI_CHECK_ARG(a && a->A_hi && a->W_hi && a->bias && gamma && beta && y_hi && stats && a->M >= 0);
     DIDI_CHECK_ARG(a->act == DIDI_ACT_NONE && !a->C_f32 && !a->C_hi && !a->C_lo && a->R_hi && !a->R_f32);
     if (!didi_gemm_ln_supported(a->M, a->N, a->K, a->precision)) return DIDI_ERR_UNSUPPORTED;
     DIDI_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K && a->ldr % 8 == 0 && a->ldr >= a->N);
     DIDI_CHECK_ARG(al16(a->A_hi) && al16(a->A_lo) && al16(a->W_hi) && al16(a->W_lo) && al16(a->bias) && al16(a->R_hi) && al16(a->R_lo));
     DIDI_CHECK_ARG(al16(gamma) && al16(beta) && al16(y_hi) && al16(y_lo) && al16(y_f32) && al16(stats));
+    DIDI_CHECK_ARG(lo_bytes >= 0 && lo_bytes <= 3 && (!(lo_bytes & 1) || a->R_lo) && (!(lo_bytes & 2) || y_lo));
+    if (lo_bytes && a->precision != DIDI_PREC_FP16 && a->precision != DIDI_PREC_FP16X2) return DIDI_ERR_UNSUPPORTED;
     if (a->M == 0) return DIDI_OK;
     const DeviceInfo* di = device_info();  // of the current device: opt-ins done, CU count known
     if (!di || di->ncu < 4) return DIDI_ERR_LAUNCH;
@@ -1995,6 +2019,7 @@ extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const f
     p.ln_gamma = gamma; p.ln_beta = beta; p.ln_eps = eps; p.tiles_n = 4; p.fault = a->fault;
     DIDI_CHECK_ARG(a->act_dither >= 0 && a->act_dither < 8192);
     p.dither = a->act_dither;
+    p.lo8 = lo_bytes;
 #ifdef DIDI_STAMPS
     p.stamps = g_stamp_buf;
 #endif
@@ -2014,8 +2039,12 @@ extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const f
         p.M = (int)std::min<size_t>((size_t)nb * 256, (size_t)a->M - r0);
         p.tiles_m = nb;
         p.A_hi = a->A_hi + r0 * a->lda; p.A_lo = (p.npass == 3 ? a->A_lo : a->A_hi) + r0 * a->lda;
-        p.R_hi = a->R_hi + r0 * a->ldr; p.R_lo = a->R_lo ? a->R_lo + r0 * a->ldr : nullptr;
-        p.C_hi = y_hi + r0 * a->N; p.C_lo = y_lo ? y_lo + r0 * a->N : nullptr; p.C_f32 = y_f32 ? y_f32 + r0 * a->N : nullptr;
+        // byte planes: the same element offsets, one byte each
+        p.R_hi = a->R_hi + r0 * a->ldr;
+        p.R_lo = !a->R_lo ? nullptr : (lo_bytes & 1) ? reinterpret_cast<const u16*>(reinterpret_cast<const uint8_t*>(a->R_lo) + r0 * a->ldr) : a->R_lo + r0 * a->ldr;
+        p.C_hi = y_hi + r0 * a->N;
+        p.C_lo = !y_lo ? nullptr : (lo_bytes & 2) ? reinterpret_cast<u16*>(reinterpret_cast<uint8_t*>(y_lo) + r0 * a->N) : y_lo + r0 * a->N;
+        p.C_f32 = y_f32 ? y_f32 + r0 * a->N : nullptr;
         p.ln_stats = reinterpret_cast<unsigned long long*>(stats) + (size_t)b0 * 4 * 512;
         const int grid = nb * 4;
         if (p.npass == 3 && p.f16) gemm_pp_kernel<3, true, true><<<grid, 512, lds, st>>>(p);
@@ -2026,6 +2055,16 @@ extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const f
         DIDI_LAUNCH_CHECK();
     }
     return DIDI_OK;
+}
+
+extern "C" int didi_gemm_ln(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, uint16_t* y_hi,
+                            uint16_t* y_lo, float* y_f32, void* stats, uint32_t epoch, void* stream) {
+    return gemm_ln_impl(a, gamma, beta, eps, y_hi, y_lo, y_f32, stats, epoch, 0, stream);
+}
+
+extern "C" int didi_gemm_ln_lo8(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, uint16_t* y_hi, void* y_lo,
+                                float* y_f32, void* stats, uint32_t epoch, int lo_bytes, void* stream) {
+    return gemm_ln_impl(a, gamma, beta, eps, y_hi, reinterpret_cast<uint16_t*>(y_lo), y_f32, stats, epoch, lo_bytes, stream);
 }
 
 // ------------------------------------------------------------------ rounding: classifier GEMM + argmax

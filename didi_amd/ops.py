@@ -117,9 +117,11 @@ def gemm(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, precision="bf16x3", residu
     return c_hi, c_lo, c_f32
 
 
-def gemm_ln(a_hi, a_lo, w_hi, w_lo, bias, residual_planes, gamma, beta, eps, precision="fp16", f32=False, out=None, fault=None):
+def gemm_ln(a_hi, a_lo, w_hi, w_lo, bias, residual_planes, gamma, beta, eps, precision="fp16", f32=False, out=None, fault=None, lo_bytes=0):
     """LayerNorm(A W^T + bias + residual) in one launch -> (y_hi, y_lo, y_f32).  N == 768, M >= 2048.
-    ``out`` = (y_hi, y_lo) to write into (may be the residual planes themselves, as the decoder does)."""
+    ``out`` = (y_hi, y_lo) to write into (may be the residual planes themselves, as the decoder does).
+    ``lo_bytes`` (fp16 / fp16x2): bit 0: residual_planes[1] is a uint8 plane, bit 1: y_lo is written as one (didi_gemm_ln_lo8);
+    residual_planes[1] None: the residual is its hi plane."""
     M, K = a_hi.shape
     N = w_hi.shape[0]
     dev = a_hi.device
@@ -129,13 +131,18 @@ def gemm_ln(a_hi, a_lo, w_hi, w_lo, bias, residual_planes, gamma, beta, eps, pre
     g.W_hi, g.W_lo, g.ldw = w_hi.data_ptr(), _lib.ptr(w_lo), w_hi.stride(0)
     g.bias, g.act = bias.data_ptr(), _lib.ACT_NONE
     g.fault = _lib.ptr(fault)
-    g.R_hi, g.R_lo, g.ldr = residual_planes[0].data_ptr(), residual_planes[1].data_ptr(), residual_planes[0].stride(0)
+    g.R_hi, g.R_lo, g.ldr = residual_planes[0].data_ptr(), _lib.ptr(residual_planes[1]), residual_planes[0].stride(0)
     pd = plane_dtype(precision)
-    y_hi, y_lo = out if out is not None else (torch.empty((M, N), dtype=pd, device=dev), torch.empty((M, N), dtype=pd, device=dev))
+    if lo_bytes & 1:
+        assert residual_planes[1].dtype == torch.uint8 and residual_planes[1].stride(0) == g.ldr
+    y_hi, y_lo = out if out is not None else (torch.empty((M, N), dtype=pd, device=dev),
+                                              torch.empty((M, N), dtype=torch.uint8 if lo_bytes & 2 else pd, device=dev))
+    if lo_bytes & 2:
+        assert y_lo.dtype == torch.uint8
     y = torch.empty((M, N), dtype=torch.float32, device=dev) if f32 else None
     stats = torch.empty(lib.didi_gemm_ln_stats_bytes(M), dtype=torch.uint8, device=dev)
-    _lib.check(lib.didi_gemm_ln(C.byref(g), gamma.data_ptr(), beta.data_ptr(), eps, y_hi.data_ptr(), y_lo.data_ptr(), _lib.ptr(y),
-                                stats.data_ptr(), 0, _lib.current_stream()), "gemm_ln")
+    _lib.check(lib.didi_gemm_ln_lo8(C.byref(g), gamma.data_ptr(), beta.data_ptr(), eps, y_hi.data_ptr(), _lib.ptr(y_lo), _lib.ptr(y),
+                                    stats.data_ptr(), 0, lo_bytes, _lib.current_stream()), "gemm_ln")
     return y_hi, y_lo, y
 
 

@@ -81,7 +81,11 @@ enum {
     DIDI_OPT_HI_RESIDUAL = 9,  /* 1: in DIDI_PREC_FP16 (one-product) decoder calls the residual stream between the fused projection +
                                   LayerNorm launches travels as its fp16 hi plane alone (12 bits; the remainder plane is neither written
                                   nor re-joined): half the bytes of those launches' epilogues.  0 (default): hi + lo everywhere */
-    DIDI_OPT_COUNT = 10
+    DIDI_OPT_LO8_RESIDUAL = 10, /* 1 (default): in DIDI_PREC_FP16 / DIDI_PREC_FP16X2 decoder calls (no GEMM there multiplies an activation's
+                                  remainder plane) the remainder of the residual stream travels between the fused projection + LayerNorm
+                                  launches as BYTES (didi_gemm_ln_lo8: hi + lo8, 14 bits and more): 3 instead of 4 bytes per value and
+                                  direction in the launches whose epilogues those bytes bound.  0: 16-bit remainder plane everywhere */
+    DIDI_OPT_COUNT = 11
 };
 int didi_set_option(int key, int value);
 int didi_get_option(int key, int* value);
@@ -283,6 +287,16 @@ int didi_qkv_self_attention(const didi_gemm_args* a, int heads, int S, float sca
 int didi_q_cross_attention_supported(int M, int H, int heads, int S, int C, int K, int precision);
 int didi_q_cross_attention(const didi_gemm_args* a, const uint16_t* K_hi, const uint16_t* V_hi, int ldkv, const int32_t* key_mask,
                            const int32_t* key_count, int heads, int S, int C, float scale, void* stream);
+
+/* didi_gemm_ln with the remainder plane of the residual and / or of the output as BYTES (no reference counterpart: the reference
+ * keeps fp32 hidden states, HF:models/bert/modeling_bert.py:284-295; this is how the engine carries them between the launches
+ * of a one- or two-product fp16 call).  lo_bytes bit 0: a->R_lo points to a byte plane [M, ldr]; bit 1: y_lo is written as a
+ * byte plane [M, N].  byte = top byte (sign, 5 exponent, 2 mantissa bits) of fp16(256 * (v - hi)), rounded half away from zero;
+ * the residual re-joins as hi + fp16(byte << 8) / 256.  DIDI_PREC_FP16 / DIDI_PREC_FP16X2 only (else DIDI_ERR_UNSUPPORTED);
+ * a NULL a->R_lo means "the residual is its hi plane", a NULL y_lo "write no remainder plane" (both also in didi_gemm_ln).
+ * lo_bytes = 0 is didi_gemm_ln. */
+int didi_gemm_ln_lo8(const didi_gemm_args* a, const float* gamma, const float* beta, float eps, uint16_t* y_hi, void* y_lo,
+                     float* y_f32, void* stats, uint32_t epoch, int lo_bytes, void* stream);
 
 /* Small batches (M < 2048 rows: interactive use, a handful of dialogs).  The same arithmetic as didi_gemm (+ an
  * optional LayerNorm over the N output columns: gamma/beta non-NULL, as didi_gemm_ln), organised for latency: K is split

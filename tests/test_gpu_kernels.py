@@ -329,6 +329,50 @@ def test_gemm_ln_fused(ops, M, K, precision):
     assert torch.equal(h_hi, y_hi) and torch.equal(h_lo, y_lo)
 
 
+@pytest.mark.parametrize("precision", ["fp16", "fp16x2"])
+def test_gemm_ln_remainder_plane_as_bytes(ops, precision):
+    """didi_gemm_ln_lo8: the residual stream's remainder plane as bytes (top byte of fp16(256 * (v - hi))), as the engine carries
+    it between the fused launches of a one- / two-product call.  Written bytes decode to the remainder within the format's
+    1 / 8 (3 significant bits) or 2^-25 absolute; the hi plane and the fp32 output are those of didi_gemm_ln; a byte-plane
+    residual gives the output of the 16-bit-plane residual holding the same values; in place; other precisions refused."""
+    M, N, K = 2100, 768, 768
+    a, w, bias, r = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=0.05), rnd(N, seed=33), rnd(M, N, seed=34)
+    r[:, 5] += 30.0
+    r[:, 7] *= 1e-3  # small values: remainders far below fp16's normal range
+    g, b = (1 + rnd(N, seed=35, scale=0.1)).cuda(), rnd(N, seed=36, scale=0.1).cuda()
+    a_hi, a_lo = ops.split(a.cuda(), dtype=torch.float16)
+    w_hi, w_lo = ops.split(w.cuda(), dtype=torch.float16)
+    rp = ops.split(r.cuda(), dtype=torch.float16)
+    y_hi, y_lo, y = ops.gemm_ln(a_hi, a_lo, w_hi, w_lo, bias.cuda(), rp, g, b, 1e-12, precision=precision, f32=True)
+    z_hi, z_b, z = ops.gemm_ln(a_hi, a_lo, w_hi, w_lo, bias.cuda(), rp, g, b, 1e-12, precision=precision, f32=True, lo_bytes=2)
+    assert z_b.dtype == torch.uint8 and torch.equal(z_hi, y_hi) and torch.equal(z, y)
+    dec = (z_b.to(torch.int16) << 8).view(torch.float16).double() / 256.0  # what the next launch re-joins
+    rem = y.double() - y_hi.double()
+    err = (dec - rem).abs()
+    assert bool((err <= rem.abs() / 8 + 2.0 ** -25).all()), (err - rem.abs() / 8).max().item()
+    assert rel_l2(y_hi.double() + dec, y) <= 2e-5  # 16-bit remainder plane: 2e-5 too (its own test); hi alone: 2.6e-4
+    assert rel_l2(y_hi.double(), y) >= 1e-4
+    # the byte plane as the residual of the next launch == a 16-bit plane holding the same remainders (exactly representable here:
+    # |remainder| >= 2^-24 * 256 or zero is not guaranteed, so compare with a tolerance far below the plane's own step)
+    lo16 = dec.to(torch.float16)
+    want_hi, _, want = ops.gemm_ln(a_hi, a_lo, w_hi, w_lo, bias.cuda(), (y_hi, lo16), g, b, 1e-12, precision=precision, f32=True)
+    got_hi, got_b, got = ops.gemm_ln(a_hi, a_lo, w_hi, w_lo, bias.cuda(), (y_hi, z_b), g, b, 1e-12, precision=precision, f32=True, lo_bytes=3)
+    assert rel_l2(got, want) <= 1e-6 and (got_hi != want_hi).float().mean().item() <= 1e-3
+    # in place over the residual, as the engine runs it
+    h_hi, h_b = y_hi.clone(), z_b.clone()
+    ops.gemm_ln(a_hi, a_lo, w_hi, w_lo, bias.cuda(), (h_hi, h_b), g, b, 1e-12, precision=precision, out=(h_hi, h_b), lo_bytes=3)
+    assert torch.equal(h_hi, got_hi) and torch.equal(h_b, got_b)
+    # residual as its hi plane alone, no remainder plane written
+    n_hi, n_lo, n = ops.gemm_ln(a_hi, a_lo, w_hi, w_lo, bias.cuda(), (y_hi, None), g, b, 1e-12, precision=precision, f32=True, out=(torch.empty_like(y_hi), None))
+    zero = torch.zeros_like(y_hi)
+    w0_hi, _, w0 = ops.gemm_ln(a_hi, a_lo, w_hi, w_lo, bias.cuda(), (y_hi, zero), g, b, 1e-12, precision=precision, f32=True)
+    assert n_lo is None and torch.equal(n, w0) and torch.equal(n_hi, w0_hi)
+    with pytest.raises(RuntimeError):
+        b_hi, b_lo = ops.split(a.cuda(), dtype=torch.bfloat16)
+        ops.gemm_ln(b_hi, b_lo, *ops.split(w.cuda(), dtype=torch.bfloat16), bias.cuda(), ops.split(r.cuda(), dtype=torch.bfloat16), g, b, 1e-12,
+                    precision="bf16x3", lo_bytes=2)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 768, 768), (2304, 8008, 768), (63, 768, 768)])
 def test_gemm_and_rounding_fp16x3(ops, M, N, K):
     """DIDI_PREC_FP16X3 (all three products on fp16 planes, ~22 bits; the final rounding / logits of the fp16x2 mode): 128x128 tile,

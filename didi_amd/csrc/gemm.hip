@@ -720,6 +720,14 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #endif
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * BBN;
+    if constexpr (!LN && !AMAX && ATTN == 0) {
+        if (p.k_split) {  // split-K form (didi_gemm_small on weight-gradient shapes): K columns [y k_split, ...), raw partial sums
+            const int k0 = blockIdx.y * p.k_split;
+            p.A_hi += k0; p.A_lo += k0; p.W_hi += k0; p.W_lo += k0;
+            p.K = min(p.k_split, p.K - k0);
+            p.C_f32 += (size_t)blockIdx.y * p.M * p.ldc;
+        }
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -1808,6 +1816,12 @@ extern "C" int didi_q_cross_attention(const didi_gemm_args* a, const uint16_t* K
 // M = 63 whatever the shape, with 90 % of the chip idle.  Here K is cut into chunks so that >= ~256 workgroups run, the
 // raw partial sums go to a workspace (L2-resident: <= 64 KiB per workgroup), and ONE row kernel adds them up and applies
 // bias, activation, residual and, for the output projections, LayerNorm -- so the separate LayerNorm pass goes away too.
+// weight-gradient shapes with enough rows for the 256x192 tile: its staggered K-loop multiplies ~1.6x faster than the 128x128
+// tile's, which pays for the extra splits (fewer, larger tiles -> more K-splits to fill the CUs -> more partial sums)
+static bool small_uses_big_tile(int M, int N, int K) {
+    return K >= 8192 && M >= 512 && N >= BBN && N % 8 == 0 && (long)cdiv(N, BBN) * BBN * 100 <= (long)N * 115 && cdiv(M, 256) * cdiv(N, BBN) < 128 &&
+           didi_opt(DIDI_OPT_GEMM_BIG) != 0 && didi_opt(DIDI_OPT_GEMM_PP) != 0;
+}
 static int small_splits(int M, int N, int K, int precision) {
     const int max_m = didi_opt(DIDI_OPT_SMALL_MAX_M);  // tuning knob
     if (M <= 0 || N % 4 != 0 || N > 3072) return 0;
@@ -1817,7 +1831,7 @@ static int small_splits(int M, int N, int K, int precision) {
     const int unit = 128;  // K columns per split are a multiple of this (two one-product K-tiles, four bf16x3 ones)
     if (K % unit != 0 || K < 2 * unit) return 0;
     if (precision != DIDI_PREC_BF16 && precision != DIDI_PREC_FP16 && precision != DIDI_PREC_BF16X3 && precision != DIDI_PREC_FP16X2 && precision != DIDI_PREC_FP16X3) return 0;
-    const int wgs = cdiv(M, BM) * cdiv(N, BN);
+    const int wgs = small_uses_big_tile(M, N, K) ? cdiv(M, 256) * cdiv(N, BBN) : cdiv(M, BM) * cdiv(N, BN);
     int ks = std::min(cdiv(256, wgs), K / unit);
     if (ks < 2) return 0;
     const int kc = cdiv(K / unit, ks) * unit;
@@ -1966,12 +1980,22 @@ extern "C" int didi_gemm_small(const didi_gemm_args* a, const float* gamma, cons
     p.k_split = cdiv(a->K / 128, ks) * 128;
     p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
     hipStream_t st = as_stream(stream);
+    if (small_uses_big_tile(a->M, a->N, a->K) && allow_big_lds()) {  // raw partial sums out of the staggered 256x192 kernel
+        p.tiles_m = cdiv(a->M, 256); p.tiles_n = cdiv(a->N, BBN);
+        const dim3 grid_pp(p.tiles_m * p.tiles_n, ks);
+        if (p.npass == 3 && p.f16) gemm_pp_kernel<3, true, false><<<grid_pp, 512, PP_LDS_BYTES, st>>>(p);
+        else if (p.npass == 3) gemm_pp_kernel<3, false, false><<<grid_pp, 512, PP_LDS_BYTES, st>>>(p);
+        else if (p.npass == 2) gemm_pp_kernel<2, true, false><<<grid_pp, 512, PP_LDS_BYTES, st>>>(p);
+        else if (p.f16) gemm_pp_kernel<1, true, false><<<grid_pp, 512, PP_LDS_BYTES, st>>>(p);
+        else gemm_pp_kernel<1, false, false><<<grid_pp, 512, PP_LDS_BYTES, st>>>(p);
+    } else {
     const dim3 grid(p.tiles_m * p.tiles_n, ks);
     if (p.npass == 3 && p.f16) gemm_kernel<3, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
     else if (p.npass == 3) gemm_kernel<3, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
     else if (p.npass == 2) gemm_kernel<2, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
     else if (p.f16) gemm_kernel<1, 2, true><<<grid, 256, SMEM_BYTES, st>>>(p);
     else gemm_kernel<1, 2, false><<<grid, 256, SMEM_BYTES, st>>>(p);
+    }
     DIDI_LAUNCH_CHECK();
     RowsParams r{};
     r.part = reinterpret_cast<const float*>(workspace); r.ks = ks; r.M = a->M; r.N = a->N;

@@ -271,6 +271,28 @@ def test_gemm_small_batch_form(ops, M, N, K, precision, ln):
         assert rel_l2(c, plain) <= 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(768, 768, 16384), (2304, 768, 8192), (700, 3072, 16384), (3072, 768, 16512)])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x2"])
+def test_gemm_split_k_on_the_big_tile(ops, M, N, K, precision):
+    """Weight-gradient shapes (a few thousand rows, K = the batch's rows): didi_gemm_small takes its partial sums from the staggered
+    256x192 kernel (grid.y = K-splits).  Against fp64 on the same rounded operands, a ragged last row band (700), a last split
+    shorter than the others (16512 = 129 x 128), and against the plain launch to summation-order rounding."""
+    from didi_amd._lib import lib
+
+    a, w, bias = rnd(M, K, seed=47), rnd(N, K, seed=48, scale=0.05), rnd(N, seed=49)
+    pd = PD[precision]
+    ws = lib.didi_gemm_small_workspace_bytes(M, N, K, ops.PRECISIONS[precision])
+    assert ws > 0 and ws % (M * N * 4) == 0 and ws // (M * N * 4) >= 256 // (((M + 255) // 256) * (N // 192)) - 1
+    a_hi, a_lo = ops.split(a.cuda(), dtype=pd)
+    w_hi, w_lo = ops.split(w.cuda(), dtype=pd)
+    _, _, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), precision=precision, out_f32=True, out_planes=False, small=())
+    ar, wr = (ops.join(a_hi, a_lo).cpu(), ops.join(w_hi, w_lo).cpu()) if precision == "bf16x3" else ref_operands(precision, a, w, a_hi, w_hi, w_lo)
+    want = _gemm_ref(ar, wr, bias, None, None)
+    assert rel_l2(c, want) <= 5e-6, rel_l2(c, want)
+    _, _, plain = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), precision=precision, out_f32=True, out_planes=False)
+    assert rel_l2(c, plain) <= 2e-6
+
+
 def test_gemm_small_batch_form_limits(ops):
     from didi_amd._lib import lib
 

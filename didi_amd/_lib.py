@@ -24,7 +24,7 @@ ACT_NONE, ACT_GELU, ACT_TANH, ACT_RELU, ACT_GELU_NEW = 0, 1, 2, 3, 4
 STEP_NONE, STEP_INIT, STEP_DDPM, STEP_EULER = 0, 1, 2, 3
 ERR_FAULT = -5
 FAULT_LN_EXCHANGE, FAULT_FP16_RANGE = 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 # didi_set_option keys (tuning switches for A/B runs; defaults = production path)
 OPTIONS = {"GEMM_LN": 0, "GEMM_SMALL": 1, "GEMM_BIG": 2, "GEMM_PP": 3, "GEMM_MT": 4, "BIG_MIN_M": 5, "SMALL_MAX_M": 6, "X2_GEMMS": 7, "FUSED_ATTN": 8, "HI_RESIDUAL": 9, "LO8_RESIDUAL": 10}
 
@@ -192,7 +192,7 @@ SYMBOLS = [
     ("didi_axpby", C.c_int, [C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("didi_ce_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     ("didi_act_forward", C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    ("didi_embedding_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("didi_embedding_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_int64, C.c_void_p, C.c_void_p]),
     ("didi_attention_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
@@ -202,8 +202,8 @@ SYMBOLS = [
     ("didi_adamw_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     ("didi_sumsq_accumulate", C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
-    ("didi_train_embed_sum", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                       C.c_void_p]),
+    ("didi_train_embed_sum", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p]),
     ("didi_seq_sum", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("didi_train_target_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -411,10 +411,13 @@ __global__ void __launch_bounds__(256) ce_backward_kernel(float* logits, const i
     s = (red[0] + red[1]) + (red[2] + red[3]);
     const float inv = keep ? scale / s : 0.f;
     const int64_t tg = targets[blockIdx.x];
-    if (nll && threadIdx.x == 0) nll[blockIdx.x] = keep ? __logf(s) + mx - row[tg] : 0.f;
+    // a target outside [0, V) (vocabulary mismatch, an ignore_index such as -100 on a row the mask keeps): the row gets +inf as its
+    // term -- the step's loss shows it, as didi_round_ce defines the case -- and no gradient; nothing is read or written out of bounds
+    const bool tg_ok = tg >= 0 && tg < V;
+    if (nll && threadIdx.x == 0) nll[blockIdx.x] = keep ? (tg_ok ? __logf(s) + mx - row[tg] : INFINITY) : 0.f;
     __syncthreads();  // the target's logit is read before any lane overwrites it
     for (int n = threadIdx.x; n < V; n += 256) {
-        float g = keep ? __expf(row[n] - mx) * inv : 0.f;
+        float g = keep && tg_ok ? __expf(row[n] - mx) * inv : 0.f;
         if (keep && n == tg) g -= scale;
         row[n] = g;
     }
@@ -430,20 +433,20 @@ extern "C" int didi_ce_backward(float* logits, const int64_t* targets, const int
 
 // ------------------------------------------------------------------ embedding gradients: table_grad[ids[m], :] += scale * dy[m, :]
 // nn.Embedding backward (float atomics: rows repeat within a batch); rows equal to `skip_id` (padding_idx, model.py:104) get none.
-__global__ void __launch_bounds__(256) embedding_backward_kernel(const int64_t* ids, const float* dy, int M, int H, float scale,
+__global__ void __launch_bounds__(256) embedding_backward_kernel(const int64_t* ids, const float* dy, int M, int H, int64_t V, float scale,
                                                                  int64_t skip_id, float* grad) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const int64_t id = ids[m];
-    if (id == skip_id) return;
+    if (id == skip_id || id < 0 || id >= V) return;  // ids outside the table get no gradient (and write nothing)
     for (int c = lane; c < H; c += 64) atomicAdd(grad + (size_t)id * H + c, scale * dy[(size_t)m * H + c]);
 }
-extern "C" int didi_embedding_backward(const int64_t* ids, const float* dy, int M, int H, float scale, int64_t skip_id, float* grad,
+extern "C" int didi_embedding_backward(const int64_t* ids, const float* dy, int M, int H, int64_t V, float scale, int64_t skip_id, float* grad,
                                        void* stream) {
-    DIDI_CHECK_ARG(ids && dy && grad && M >= 0 && H > 0);
+    DIDI_CHECK_ARG(ids && dy && grad && M >= 0 && H > 0 && V > 0);
     if (M == 0) return DIDI_OK;
-    embedding_backward_kernel<<<cdiv(M, 4), 256, 0, as_stream(stream)>>>(ids, dy, M, H, scale, skip_id, grad);
+    embedding_backward_kernel<<<cdiv(M, 4), 256, 0, as_stream(stream)>>>(ids, dy, M, H, V, scale, skip_id, grad);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }
@@ -838,23 +841,25 @@ extern "C" int didi_sumsq_accumulate(const float* x, size_t n, float* out, void*
 // HF:models/bert/modeling_bert.py:95-115).  The sampler fuses this into its LayerNorm kernel; training keeps the LayerNorm INPUT
 // because the backward needs it.
 __global__ void __launch_bounds__(256) train_embed_sum_kernel(const float* xt, const float* te, const int64_t* t, const float* pos,
-                                                              const float* tok0, int S, int H4, size_t n4, float* out) {
+                                                              const float* tok0, int S, int H4, int T_rows, size_t n4, float* out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const int c = (int)(i % H4);
     const size_t row = i / H4;
     const int s = (int)(row % S);
     const int64_t tb = t[row / S];
-    const float4 a = reinterpret_cast<const float4*>(xt)[i], b = reinterpret_cast<const float4*>(te)[(size_t)tb * H4 + c],
+    const float nan_ = __builtin_nanf("");  // a timestep outside the table poisons its dialog instead of reading out of bounds
+    const float4 a = reinterpret_cast<const float4*>(xt)[i],
+                 b = tb >= 0 && tb < T_rows ? reinterpret_cast<const float4*>(te)[(size_t)tb * H4 + c] : make_float4(nan_, nan_, nan_, nan_),
                  p = reinterpret_cast<const float4*>(pos)[(size_t)s * H4 + c], k = reinterpret_cast<const float4*>(tok0)[c];
     reinterpret_cast<float4*>(out)[i] = make_float4(a.x + b.x + p.x + k.x, a.y + b.y + p.y + k.y, a.z + b.z + p.z + k.z, a.w + b.w + p.w + k.w);
 }
 extern "C" int didi_train_embed_sum(const float* x_t, const float* time_embeds, const int64_t* t, const float* pos_emb, const float* tok0,
-                                    int B, int S, int H, float* out, void* stream) {
-    DIDI_CHECK_ARG(x_t && time_embeds && t && pos_emb && tok0 && out && B >= 0 && S > 0 && H > 0 && H % 4 == 0);
+                                    int B, int S, int H, int T_rows, float* out, void* stream) {
+    DIDI_CHECK_ARG(x_t && time_embeds && t && pos_emb && tok0 && out && B >= 0 && S > 0 && H > 0 && H % 4 == 0 && T_rows > 0);
     const size_t n4 = (size_t)B * S * (H / 4);
     if (n4 == 0) return DIDI_OK;
-    train_embed_sum_kernel<<<(unsigned)cdiv((long)n4, 256), 256, 0, as_stream(stream)>>>(x_t, time_embeds, t, pos_emb, tok0, S, H / 4, n4, out);
+    train_embed_sum_kernel<<<(unsigned)cdiv((long)n4, 256), 256, 0, as_stream(stream)>>>(x_t, time_embeds, t, pos_emb, tok0, S, H / 4, T_rows, n4, out);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

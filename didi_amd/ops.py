@@ -332,7 +332,7 @@ def transpose_split_colsum(x, dtype=torch.bfloat16):
     return hi, lo, out
 
 
-def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, residual=None):
+def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, residual=None, fault=None):
     """Backward of C = A W^T + b (nn.Linear): dC [M,N], A [M,K], W [N,K] fp32 -> (dA [M,K] (+ residual), dW [N,K], db [N] or None).
     dgrad and wgrad are didi_gemm launches on transposed operand planes; db comes out of the pass that transposes dC.
     ``residual`` fp32 [M,K]: added to dA in the dgrad GEMM's epilogue (the gradient of a skip connection joining there)."""
@@ -347,7 +347,7 @@ def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, resid
         z = torch.zeros((M, pad), dtype=torch.float32, device=dC.device)
         z[:, :N] = dC
         dc_hi, dc_lo = split(z, dtype=pd)
-    dA = gemm(dc_hi, dc_lo, wt_hi, wt_lo, precision=precision, out_f32=True, out_planes=False, residual=residual)[2] if need_dA else None
+    dA = gemm(dc_hi, dc_lo, wt_hi, wt_lo, precision=precision, out_f32=True, out_planes=False, residual=residual, fault=fault)[2] if need_dA else None
     if bias:
         dct_hi, dct_lo, db = transpose_split_colsum(dC, dtype=pd)  # [N, M8] + the bias gradient
     else:
@@ -355,7 +355,7 @@ def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, resid
     at_hi, at_lo = transpose_split(A, dtype=pd)          # [K, M8]
     # wgrad: few output tiles, K = the batch's rows -> the split-K form wherever it applies
     use_small = lib.didi_gemm_small_workspace_bytes(N, K, dct_hi.shape[1], _prec(precision)) > 0
-    _, _, dW = gemm(dct_hi, dct_lo, at_hi, at_lo, precision=precision, out_f32=True, out_planes=False, small=() if use_small else None)
+    _, _, dW = gemm(dct_hi, dct_lo, at_hi, at_lo, precision=precision, out_f32=True, out_planes=False, small=() if use_small else None, fault=fault)
     return dA, dW, db
 
 
@@ -400,13 +400,13 @@ def act_forward(act, x, dtype=torch.bfloat16, f32=True):
 
 
 def embedding_backward(ids, dy, grad, scale=1.0, skip_id=-1):
-    """grad[ids[m], :] += scale * dy[m, :] (fp32 atomics); rows with id == skip_id get nothing."""
+    """grad[ids[m], :] += scale * dy[m, :] (fp32 atomics); rows with id == skip_id, or outside the table, get nothing."""
     ids = ids.reshape(-1).to(torch.int64).contiguous()
     dy = _f32c(dy)
     H = dy.shape[-1]
     assert grad.is_contiguous() and grad.dtype == torch.float32 and grad.shape[-1] == H and dy.numel() == ids.numel() * H
-    _lib.check(lib.didi_embedding_backward(ids.data_ptr(), dy.data_ptr(), ids.numel(), H, float(scale), int(skip_id), grad.data_ptr(),
-                                           _lib.current_stream()), "embedding_backward")
+    _lib.check(lib.didi_embedding_backward(ids.data_ptr(), dy.data_ptr(), ids.numel(), H, grad.numel() // H, float(scale), int(skip_id),
+                                           grad.data_ptr(), _lib.current_stream()), "embedding_backward")
     return grad
 
 
@@ -482,8 +482,9 @@ def train_embed_sum(x_t, time_embeds, t, pos_emb, tok0):
     t = t.reshape(-1).to(torch.int64).contiguous()
     assert t.numel() == B and pos_emb.shape[0] >= S
     out = torch.empty_like(x_t)
+    assert time_embeds.is_contiguous() and time_embeds.shape[-1] == H
     _lib.check(lib.didi_train_embed_sum(x_t.data_ptr(), time_embeds.data_ptr(), t.data_ptr(), pos_emb.data_ptr(), tok0.data_ptr(), B, S, H,
-                                        out.data_ptr(), _lib.current_stream()), "train_embed_sum")
+                                        time_embeds.shape[0], out.data_ptr(), _lib.current_stream()), "train_embed_sum")
     return out
 
 

@@ -73,6 +73,8 @@ class DiDiTrainer:
             raise NotImplementedError("freeze_encoder=False (src/diffusion/model.py:112-115,184-188 back-propagates into the context "
                                       "encoder) is not built: the backward stops at the adapter input; both shipped configs freeze the encoder")
         self.cfg, self.device, self.precision = cfg, torch.device(device), precision
+        # device fault word of the step's GEMMs: fp16-plane precisions only (bf16 planes cannot overflow where fp32 does not)
+        self.fault = ops.new_fault(self.device) if ops.plane_dtype(precision) == torch.float16 else None
         self.hidden_dropout, self.attention_dropout = float(hidden_dropout), float(attention_dropout)
         self.anchor_loss, self.noise_factor = bool(anchor_loss), float(noise_factor)
         self.opt = dict(DEFAULT_OPT, **(opt_kwargs or {}))
@@ -210,10 +212,20 @@ class DiDiTrainer:
 
     # ------------------------------------------------------------------ forward + backward
     def _linear(self, w, a_hi, a_lo, **kw):
-        return ops.gemm(a_hi, a_lo, w.hi, w.lo, bias=w.b, precision=self.precision, out_f32=True, **kw)
+        return ops.gemm(a_hi, a_lo, w.hi, w.lo, bias=w.b, precision=self.precision, out_f32=True, fault=self.fault, **kw)
 
     def _linear_bwd(self, dC, A, w, residual=None, need_dA=True):
-        return ops.linear_backward(dC, A, w.w, precision=self.precision, residual=residual, need_dA=need_dA)
+        return ops.linear_backward(dC, A, w.w, precision=self.precision, residual=residual, need_dA=need_dA, fault=self.fault)
+
+    def check_fault(self, what="training step"):
+        """fp16 planes only: wait for the stream and raise if a GEMM of the step wrote a value beyond fp16's range into a plane
+        (the planes saturate at +-65504: under the fixed loss scale a saturated activation or gradient would otherwise pass
+        unnoticed).  forward_backward calls it once per step."""
+        if self.fault is not None:
+            try:
+                _lib.check_fault(self.fault, what)
+            finally:
+                self.fault.zero_()
 
     @torch.no_grad()
     def forward_backward(self, raw_context, target, *, draws=None, t=None, keep=False, dropout_seed=None, grad_sink=None):
@@ -345,7 +357,7 @@ class DiDiTrainer:
 
         def logits_of(x2d):
             hi, lo = ops.split(x2d, dtype=pd)
-            _, _, lg = ops.gemm(hi, lo, self._cls.hi, self._cls.lo, precision=self.precision, out_f32=True, out_planes=False)
+            _, _, lg = ops.gemm(hi, lo, self._cls.hi, self._cls.lo, precision=self.precision, out_f32=True, out_planes=False, fault=self.fault)
             return lg
 
         def ce_and_grad(x2d):
@@ -460,6 +472,7 @@ class DiDiTrainer:
         elif ls != 1.0:
             for g_ in G.values():
                 ops.axpby(0.0, g_, 1.0 / ls, g_)
+        self.check_fault()
         out = dict(mse=mse, ce=ce, t_T=t_T, loss=loss, ce_hat=ce_hat, grads=G, t=t)
         if keep:
             out.update(emb=emb, x_0=x_0, x_t=x_t, x_0_hat=x_0_hat, d_x_0_hat=d_x0_hat.view(B, S, H) / ls)

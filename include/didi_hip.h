@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DIDI_ABI_VERSION 5
+#define DIDI_ABI_VERSION 6
 
 enum {
     DIDI_OK = 0,
@@ -597,7 +597,8 @@ int didi_axpby(float a, const float* x, float b, float* y, size_t n, void* strea
 /* nll (nullable) fp32 [M]: the per-token cross-entropy terms (0 on masked rows), from the same pass. */
 int didi_ce_backward(float* logits, const int64_t* targets, const int64_t* mask, int M, int V, float scale, float* nll, void* stream);
 /* nn.Embedding backward: grad[ids[m], :] += scale * dy[m, :] (float atomics); rows with id == skip_id (padding_idx) get none. */
-int didi_embedding_backward(const int64_t* ids, const float* dy, int M, int H, float scale, int64_t skip_id, float* grad, void* stream);
+int didi_embedding_backward(const int64_t* ids, const float* dy, int M, int H, int64_t V, float scale, int64_t skip_id, float* grad,
+                            void* stream); /* V: rows of the table; ids outside [0, V) get no gradient */
 /* Attention backward without dropout (= didi_attention_train_backward with drop_p = 0): dQ, dK, dV from dO, P recomputed. */
 int didi_attention_backward(const float* Q, const float* K, const float* V, const float* dO, const int32_t* key_mask, int B, int heads,
                             int Sq, int Sk, int D, int ldq, int ldk, int ldv, int ldo, int causal, float scale, float* dQ, float* dK,
@@ -639,7 +640,7 @@ int didi_sumsq_accumulate(const float* x, size_t n, float* out, void* stream);
 /* Decoder input of the training forward in fp32 (the LayerNorm INPUT, which the backward needs):
  * out[b,s,:] = x_t[b,s,:] + time_embeds[t[b],:] + pos_emb[s,:] + tok0 (src/diffusion/model.py:190-191 + BertEmbeddings). t: int64 [B]. */
 int didi_train_embed_sum(const float* x_t, const float* time_embeds, const int64_t* t, const float* pos_emb, const float* tok0, int B, int S,
-                         int H, float* out, void* stream);
+                         int H, int T_rows, float* out, void* stream); /* T_rows: rows of time_embeds; a t outside [0, T_rows) gives NaN rows */
 /* out[b, :] = sum_s x[b, s, :] (fp32 [B,S,H] -> [B,H]): per-dialog sums that scatter into the time-embedding rows. */
 int didi_seq_sum(const float* x, int B, int S, int H, float* out, void* stream);
 /* Gradient arriving at the target embeddings (src/diffusion/model.py:202-235), one pass:

@@ -119,6 +119,44 @@ def test_embedding_backward_repeats_and_padding():
     assert float(grad.abs().max()) <= 1e-5
 
 
+def test_out_of_range_ids_and_timesteps_touch_nothing():
+    """An id outside the table (vocabulary mismatch, ignore_index = -100) or a timestep outside time_embeds must not become an
+    out-of-bounds device access: embedding_backward skips the row, ce_backward gives the row +inf and no gradient (the case as
+    didi_round_ce defines it), train_embed_sum poisons the dialog with NaN."""
+    from didi_amd import ops
+
+    g = torch.Generator().manual_seed(14)
+    V, H = 50, 128
+    ids = torch.randint(0, V, (4, 9), generator=g)
+    dy = torch.randn(4, 9, H, generator=g)
+    bad = ids.clone()
+    bad[0, 0], bad[1, 3], bad[2, 2] = -100, V, 10 ** 12
+    ok_rows = (bad == ids)
+    guard = torch.full((V + 8, H), 7.0, device="cuda")  # the table sits inside a larger allocation: writes past it would show
+    grad = guard[:V]
+    grad.zero_()
+    ops.embedding_backward(bad.cuda(), dy.cuda(), grad)
+    want = torch.zeros(V, H, dtype=torch.float64)
+    want.index_add_(0, ids[ok_rows], dy[ok_rows].double())
+    assert rel_l2(grad, want) <= 1e-6 and float((guard[V:] - 7.0).abs().max()) == 0.0
+    # cross-entropy backward: rows 0 and 2 carry targets outside [0, V)
+    logits = torch.randn(5, V, generator=g)
+    targets = torch.tensor([-100, 3, V, 7, 9])
+    mask = torch.tensor([1, 1, 1, 0, 1])
+    dev, nll = ops.ce_backward(logits.cuda().clone(), targets.cuda(), mask.cuda(), 1.0)
+    assert torch.isinf(nll[0]) and torch.isinf(nll[2]) and float(nll[3]) == 0.0 and bool(torch.isfinite(nll[[1, 4]]).all())
+    assert float(dev[[0, 2, 3]].abs().max()) == 0.0
+    ref = torch.softmax(logits.double(), -1)
+    ref[torch.arange(5), targets.clamp(0, V - 1)] -= 1.0
+    assert rel_l2(dev[[1, 4]], ref[[1, 4]]) <= 1e-5
+    # timesteps
+    B, S, T = 3, 5, 20
+    xt, te, pos, tok = torch.randn(B, S, H, generator=g), torch.randn(T + 1, H, generator=g), torch.randn(8, H, generator=g), torch.randn(H, generator=g)
+    tt = torch.tensor([4, T + 1, -1])
+    got = ops.train_embed_sum(xt.cuda(), te.cuda(), tt.cuda(), pos.cuda(), tok.cuda())
+    assert bool(torch.isnan(got[1:]).all()) and rel_l2(got[0], xt[0] + te[4] + pos[:S] + tok) <= 1e-7
+
+
 def test_embed_sum_seq_sum_target_backward_sumsq_axpby():
     from didi_amd import ops
 

@@ -65,11 +65,31 @@ class GemmProf:
             self.lib.didi_event_destroy(ev)
 
 
-def gemm_flops_per_call(cfg, M):
-    """Algorithmic FLOPs (2*M*N*K, NOT x3 for the split-bf16 passes) of the 6 decoder GEMMs x L, launch order."""
+def gemm_flops_per_call(cfg, M, attn_self=0.0, attn_cross=0.0):
+    """Algorithmic FLOPs (2*M*N*K, NOT x3 for the split-bf16 passes) of the 6 decoder GEMMs x L, launch order.  ``attn_self`` /
+    ``attn_cross``: algorithmic attention FLOPs that ride in the qkv / cross_q launch when the engine fuses them (fused_attention_flops)."""
     H, I = cfg.dec_dim, cfg.dec_ffn
-    per_layer = [(3 * H, H), (H, H), (H, H), (H, H), (I, H), (H, I)]
-    return [2.0 * M * n * k for _ in range(cfg.dec_layers) for n, k in per_layer]
+    per_layer = [(3 * H, H, attn_self), (H, H, 0.0), (H, H, attn_cross), (H, H, 0.0), (I, H, 0.0), (H, I, 0.0)]
+    return [2.0 * M * n * k + extra for _ in range(cfg.dec_layers) for n, k, extra in per_layer]
+
+
+def fused_attention_flops(cfg, B, S, ctx_len, precision_name, ctx_mask):
+    """(self, cross) algorithmic attention FLOPs per layer that the engine runs INSIDE the qkv / cross_q GEMM launch for this shape
+    and precision (DIDI_OPT_FUSED_ATTN; 0.0 where it runs didi_attention as a launch of its own, which the GEMM events do not
+    cover): QK^T and PV over the causal half (self) / over each dialog's visible context keys (cross)."""
+    from didi_amd import _lib, ops
+
+    opt = C.c_int()
+    _lib.check(_lib.lib.didi_get_option(_lib.OPTIONS["FUSED_ATTN"], C.byref(opt)), "get_option")
+    H, heads = cfg.dec_dim, cfg.dec_heads
+    D, M, prec = H // heads, B * S, ops.PRECISIONS[precision_name]
+    f_self = f_cross = 0.0
+    if (opt.value & 1) and _lib.lib.didi_qkv_self_attention_supported(M, H, heads, S, H, prec):
+        f_self = 2 * 2.0 * B * heads * D * (S * (S + 1) / 2)
+    if (opt.value & 2) and _lib.lib.didi_q_cross_attention_supported(M, H, heads, S, ctx_len, H, prec):
+        f_cross = 2 * 2.0 * heads * S * D * float(ctx_mask.sum())
+    return f_self, f_cross
+
 
 
 def host_cpu():
@@ -489,12 +509,18 @@ def main():
     # regime, weighted by the number of calls each regime has in the loop
     M = args.batch * S
     flops = gemm_flops_per_call(cfg, M)
+    fused = {}
     order = sorted(range(len(regimes)), key=lambda i: regimes[i][2])  # GemmProf holds the calls in increasing index
     roofline = None
     per_regime, w_time, w_flop, w_launch = {}, 0.0, 0.0, 0
     for slot, ri in enumerate(order):
         name, n_reg, call = regimes[ri]
         dur = prof.durations_ms(slot)
+        # the attention a fused launch runs is algorithmic work of that launch (about 1 % of the layer's FLOPs); un-fused, it is a
+        # launch of its own outside the GEMM events
+        fa = fused_attention_flops(cfg, args.batch, S, args.seq, name, mask[lo:hi])
+        flops = gemm_flops_per_call(cfg, M, *fa)
+        fused[name] = {"self_attention_in_qkv_launch": fa[0] > 0, "cross_attention_in_cross_q_launch": fa[1] > 0}
         if len(dur) != len(flops):
             per_regime = None
             break
@@ -526,13 +552,17 @@ def main():
                                          "layer, which carry bias + residual + LayerNorm in the epilogue)"),
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "fused_into_gemm_launches": fused,
             "launches_per_call": len(flops), "avg_launch_us": round(1e6 * w_time / w_launch, 2),
             "avg_gflop_per_launch": round(sum(flops) / len(flops) / 1e9, 2),
             "gemm_share_of_step": round(w_time / (elapsed / args.steps), 3),
             "by_precision_regime": per_regime,
             "note": ("achieved = algorithmic FLOPs (2*M*N*K per launch, the extra MFMA products of fp16x2 / x3 NOT counted) of all GEMM launches of the "
                      "loop / their summed durations: HIP events around every GEMM launch of one denoiser call per precision regime inside the "
-                     "timed region, weighted by the regime's number of calls"),
+                     "timed region, weighted by the regime's number of calls.  Since round 3 the qkv launch also runs the causal self-attention "
+                     "and the cross_q launch the cross-attention over the hoisted K / V (fused_into_gemm_launches; their ~1 % of FLOPs is counted), "
+                     "and the three output projections run bias + residual + LayerNorm in their epilogues: the durations cover all of that, so "
+                     "this figure is lower than a GEMM-only one would be while the step is faster (profiles/r03_ab_cross_fp16.log)"),
         }
     prof.close()
 

@@ -482,12 +482,78 @@ __device__ __forceinline__ void mm_tn(const float* A, int lda, const float* B, i
         }
 }
 
+// fp32 MFMA forms of the same products (MF = true: D = 64, Sk = 16 NJ = 64 or 96, Sq a multiple of 16: the training shapes).  v_mfma_f32_16x16x4_f32 multiplies fp32 operands
+// exactly and accumulates in fp32, so the 1e-5-class gradient fixtures hold as they do for the FMA loops, at ~4x fewer LDS bytes
+// per FLOP and without the FMA issue slots: lane (lr, lg) supplies A[lr][k] and B[k][lr] for one k = f(lg) per instruction and
+// receives D[4 lg + r][lr], r = 0..3.  Three operand arrangements, named by how each operand lies in LDS:
+//   mf_nt: A[i][k] = X[i0 + i][k], B[k][j] = Y[j0 + j][k]        (both along their rows: 16-byte reads, 4 k-steps each)
+//   mf_nn: A[i][k] = X[i0 + i][k], B[k][j] = Y[k][j0 + j]        (A 16-byte reads; B one word per k-step)
+//   mf_tn: A[i][k] = X[k][i0 + i], B[k][j] = Y[k][j0 + j]        (both one word per k-step)
+// FA: applied to every A element (fmaxf(., 0) where the dropped probabilities, stored negated, must read as zero).
+typedef float mf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mf4 mf_mma(float a, float b, mf4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// All NT_ column tiles are computed, without branches: the operands of one k-group are read first, then the MFMAs go out
+// interleaved over the tiles, so that consecutive instructions never depend on each other.
+template <int NT_, bool RELU_A>
+__device__ __forceinline__ void mf_nt(const float* X, int ldx, int i0, const float* Y, int ldy, int K, int lr, int lg, mf4 (&acc)[NT_]) {
+    for (int kk = 0; kk < K; kk += 16) {
+        float4 a = ld4(X + (i0 + lr) * ldx + kk + 4 * lg);
+        if (RELU_A) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+        float4 b[NT_];
+#pragma unroll
+        for (int j = 0; j < NT_; ++j) b[j] = ld4(Y + (16 * j + lr) * ldy + kk + 4 * lg);
+#pragma unroll
+        for (int j = 0; j < NT_; ++j) acc[j] = mf_mma(a.x, b[j].x, acc[j]);
+#pragma unroll
+        for (int j = 0; j < NT_; ++j) acc[j] = mf_mma(a.y, b[j].y, acc[j]);
+#pragma unroll
+        for (int j = 0; j < NT_; ++j) acc[j] = mf_mma(a.z, b[j].z, acc[j]);
+#pragma unroll
+        for (int j = 0; j < NT_; ++j) acc[j] = mf_mma(a.w, b[j].w, acc[j]);
+    }
+}
+template <int NT_, bool RELU_A>
+__device__ __forceinline__ void mf_nn(const float* X, int ldx, int i0, const float* Y, int ldy, int K, int lr, int lg, mf4 (&acc)[NT_]) {
+    for (int kk = 0; kk < K; kk += 16) {
+        float4 a = ld4(X + (i0 + lr) * ldx + kk + 4 * lg);
+        if (RELU_A) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        const float* yk = Y + (kk + 4 * lg) * ldy + lr;
+        float b[4][NT_];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < NT_; ++j) b[s][j] = yk[s * ldy + 16 * j];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < NT_; ++j) acc[j] = mf_mma(av[s], b[s][j], acc[j]);
+    }
+}
+template <int NT_, bool RELU_A>
+__device__ __forceinline__ void mf_tn(const float* X, int ldx, int i0, const float* Y, int ldy, int K, int lr, int lg, mf4 (&acc)[NT_]) {
+    for (int kk = 0; kk < K; kk += 16) {
+        float a[4], b[4][NT_];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            a[s] = X[(kk + 4 * s + lg) * ldx + i0 + lr];
+            if (RELU_A) a[s] = fmaxf(a[s], 0.f);
+#pragma unroll
+            for (int j = 0; j < NT_; ++j) b[s][j] = Y[(kk + 4 * s + lg) * ldy + 16 * j + lr];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < NT_; ++j) acc[j] = mf_mma(a[s], b[s][j], acc[j]);
+    }
+}
+
 // The training forward runs the same fp32 arrangement (FWD: Q K V in LDS, O = P V out), so that attention-probability dropout
 // (HF:bert:129, attention_probs_dropout_prob) is ONE mask definition shared by forward and backward: element (b, h, i, j) keeps
 // its probability iff word (j & 3) of Philox4x32-10(counter = offset + (((b heads + h) Sq + i) Sk4 + j) / 4, key = seed) is
 // >= p 2^32, Sk4 = Sk rounded up to 4.  In LDS a dropped probability is stored NEGATED (probabilities are >= 0, -0.0 included):
 // products that want the dropped matrix clamp at zero, the softmax backward takes |P|; kept entries are scaled by 1 / (1 - p).
-template <int NJ, bool BWD>
+template <int NJ, bool BWD, bool MF = false>
 __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_args p) {
     extern __shared__ float sm[];
     const int Sq = p.Sq, Sk = p.Sk, D = p.D;
@@ -513,7 +579,30 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
     __syncthreads();
     constexpr float NEG = -3.4028234663852886e38f;
     const float scale = p.scale;
-    // ---- scores: P[r][c] = scale q_r . k_c (+ masks); thread = rows ty + 16 i, columns tx + 16 j
+    const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    const mf4 mz = {0.f, 0.f, 0.f, 0.f};
+    // ---- scores: P[r][c] = scale q_r . k_c (+ masks); thread = rows ty + 16 i, columns tx + 16 j (MF: wave = 16-row strips)
+    if constexpr (MF) {
+        for (int i0 = 16 * wave; i0 < Sq; i0 += 64) {
+            mf4 acc[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = mz;
+            mf_nt<NJ, false>(q, LD, i0, k, LD, 64, lr, lg, acc);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                    const int c = 16 * j + lr;
+                    const bool km = p.key_mask && p.key_mask[(size_t)b * Sk + c] == 0;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int r = i0 + 4 * lg + r4;
+                        float sc = acc[j][r4] * scale;
+                        if (p.pos_bias) sc += p.pos_bias[((size_t)h * Sq + r) * Sk + c];
+                        if (km || (p.causal && c > r)) sc = fminf(sc + NEG, NEG);
+                        P[r * LP + c] = sc;
+                    }
+                }
+        }
+    } else
     for (int r0 = 0; r0 < Sq; r0 += 64) {
         float acc[4][NJ] = {};
         int ra[4], cb[NJ];
@@ -582,6 +671,18 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
     }
     if constexpr (!BWD) {
         // ---- O = dropout(P) V: rows ty + 16 i, columns n0 + 4 tx .. + 3 (n0 walks blocks of 64 columns: head dims up to 128)
+        if constexpr (MF) {
+            for (int i0 = 16 * wave; i0 < Sq; i0 += 64) {
+                mf4 acc[4] = {mz, mz, mz, mz};
+                mf_nn<4, true>(P, LP, i0, v, LD, 16 * NJ, lr, lg, acc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        p.O[((size_t)b * Sq + i0 + 4 * lg + r4) * p.ldo + h * 64 + 16 * j + lr] = acc[j][r4] * inv_keep;
+            }
+            return;
+        }
         for (int r0 = 0; r0 < Sq; r0 += 64)
             for (int n0 = 0; n0 < D; n0 += 64) {
                 const int no = min(n0 + tx * 4, D - 4);
@@ -611,6 +712,68 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
                     }
             }
         return;
+    } else if constexpr (MF) {
+        // ---- dV = dropout(P)^T dO: strips of 16 keys
+        for (int j0 = 16 * wave; j0 < Sk; j0 += 64) {
+            mf4 acc[4] = {mz, mz, mz, mz};
+            mf_tn<4, true>(P, LP, j0, g, LD, Sq, lr, lg, acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        p.dV[((size_t)b * Sk + j0 + 4 * lg + r4) * p.ldv + h * D + 16 * j + lr] = acc[j][r4] * inv_keep;
+        }
+        __syncthreads();
+        // ---- dP = (dO V^T) o mask / keep; D_i = sum_c |P| dP (a wave owns whole rows: in-lane over the column tiles, then over the
+        // 16 lanes of a row group); dS = |P| (dP - D) scale, back into P
+        for (int i0 = 16 * wave; i0 < Sq; i0 += 64) {
+            mf4 acc[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = mz;
+            mf_nt<NJ, false>(g, LD, i0, v, LD, 64, lr, lg, acc);
+            float pv[NJ][4], dr[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float sp = P[(i0 + 4 * lg + r4) * LP + 16 * j + lr];
+                        pv[j][r4] = fabsf(sp);
+                        acc[j][r4] = __builtin_signbitf(sp) ? 0.f : acc[j][r4] * inv_keep;
+                        dr[r4] += pv[j][r4] * acc[j][r4];
+                    }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                dr[r4] += __shfl_xor(dr[r4], 1, 64);
+                dr[r4] += __shfl_xor(dr[r4], 2, 64);
+                dr[r4] += __shfl_xor(dr[r4], 4, 64);
+                dr[r4] += __shfl_xor(dr[r4], 8, 64);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) P[(i0 + 4 * lg + r4) * LP + 16 * j + lr] = pv[j][r4] * (acc[j][r4] - dr[r4]) * scale;
+        }
+        __syncthreads();
+        // ---- dQ = dS K
+        for (int i0 = 16 * wave; i0 < Sq; i0 += 64) {
+            mf4 acc[4] = {mz, mz, mz, mz};
+            mf_nn<4, false>(P, LP, i0, k, LD, 16 * NJ, lr, lg, acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        p.dQ[((size_t)b * Sq + i0 + 4 * lg + r4) * p.ldq + h * D + 16 * j + lr] = acc[j][r4];
+        }
+        // ---- dK = dS^T Q
+        for (int j0 = 16 * wave; j0 < Sk; j0 += 64) {
+            mf4 acc[4] = {mz, mz, mz, mz};
+            mf_tn<4, false>(P, LP, j0, q, LD, Sq, lr, lg, acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        p.dK[((size_t)b * Sk + j0 + 4 * lg + r4) * p.ldk + h * D + 16 * j + lr] = acc[j][r4];
+        }
     } else {
         // ---- dV = dropout(P)^T dO
         for (int m0 = 0; m0 < Sk4; m0 += 64) {
@@ -730,14 +893,23 @@ static int attention_train_launch(const didi_attn_train_args* a, bool bwd, void*
     {
         std::lock_guard<std::mutex> lock(mu);
         for (const void* fn : {reinterpret_cast<const void*>(&attention_train_kernel<4, true>), reinterpret_cast<const void*>(&attention_train_kernel<6, true>),
-                               reinterpret_cast<const void*>(&attention_train_kernel<4, false>), reinterpret_cast<const void*>(&attention_train_kernel<6, false>)})
+                               reinterpret_cast<const void*>(&attention_train_kernel<4, false>), reinterpret_cast<const void*>(&attention_train_kernel<6, false>),
+                               reinterpret_cast<const void*>(&attention_train_kernel<4, true, true>), reinterpret_cast<const void*>(&attention_train_kernel<4, false, true>),
+                               reinterpret_cast<const void*>(&attention_train_kernel<6, true, true>), reinterpret_cast<const void*>(&attention_train_kernel<6, false, true>)})
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return DIDI_ERR_LAUNCH;
     }
     didi_attn_train_args p = *a;
     if (!(p.scale > 0.f)) p.scale = 1.0f / sqrtf((float)a->D);
     const dim3 grid(a->heads, a->B);
     hipStream_t st = as_stream(stream);
-    if (bwd) {
+    const bool mf = a->Sq % 16 == 0 && (a->Sk == 64 || a->Sk == 96) && a->D == 64;  // the fp32-MFMA form: the training shapes
+    if (mf && bwd) {
+        if (a->Sk == 64) attention_train_kernel<4, true, true><<<grid, 256, lds, st>>>(p);
+        else attention_train_kernel<6, true, true><<<grid, 256, lds, st>>>(p);
+    } else if (mf) {
+        if (a->Sk == 64) attention_train_kernel<4, false, true><<<grid, 256, lds, st>>>(p);
+        else attention_train_kernel<6, false, true><<<grid, 256, lds, st>>>(p);
+    } else if (bwd) {
         if (a->Sk <= 64) attention_train_kernel<4, true><<<grid, 256, lds, st>>>(p);
         else attention_train_kernel<6, true><<<grid, 256, lds, st>>>(p);
     } else {

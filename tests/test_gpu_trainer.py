@@ -25,9 +25,11 @@ def rel_l2(a, b):
 # ------------------------------------------------------------------ kernels
 @pytest.mark.parametrize("B,heads,Sq,Sk,D,causal,masked", [(3, 4, 10, 10, 32, True, False), (2, 12, 64, 64, 64, True, False),
                                                            (3, 4, 10, 12, 32, False, True), (2, 12, 64, 61, 64, False, True),
-                                                           (1, 2, 96, 96, 64, False, False), (2, 3, 7, 5, 16, False, True)])
+                                                           (1, 2, 96, 96, 64, False, False), (2, 3, 7, 5, 16, False, True),
+                                                           (2, 3, 96, 64, 64, False, True), (3, 2, 32, 80, 16, False, True), (2, 2, 48, 48, 48, True, False)])
 def test_attention_backward_vs_autograd(B, heads, Sq, Sk, D, causal, masked):
-    """Operands as thirds / halves of fused projections (row stride 3H / 2H), like the trainer passes them."""
+    """Operands as thirds / halves of fused projections (row stride 3H / 2H), like the trainer passes them.  Shapes whose Sq, Sk and D
+    are all multiples of 16 take the fp32-MFMA form of the kernel, the others the FMA loops."""
     from didi_amd import ops
 
     g = torch.Generator().manual_seed(B * 100 + Sq)
@@ -359,7 +361,8 @@ def test_hidden_dropout_mask_is_the_documented_philox_stream():
 
 @pytest.mark.parametrize("B,heads,Sq,Sk,D,causal,masked,p", [(3, 4, 10, 10, 32, True, False, 0.1), (2, 12, 64, 64, 64, True, False, 0.2),
                                                              (3, 4, 10, 13, 32, False, True, 0.1), (2, 3, 70, 90, 64, False, True, 0.3),
-                                                             (2, 4, 24, 24, 32, True, False, 0.0)])
+                                                             (2, 4, 24, 24, 32, True, False, 0.0), (2, 2, 64, 80, 32, False, True, 0.2),
+                                                             (1, 3, 96, 96, 64, True, False, 0.1)])
 def test_attention_train_forward_backward_with_dropout_vs_autograd(B, heads, Sq, Sk, D, causal, masked, p):
     """O = dropout(softmax(...)) V and its backward against torch autograd in fp64 fed the SAME mask, which is rebuilt on the host
     from the documented Philox stream."""

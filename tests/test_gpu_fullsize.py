@@ -188,6 +188,59 @@ def test_bench_shape_single_call_full_chip():
         del model
 
 
+@pytest.mark.parametrize("precision", ["fp16", "fp16x2"])
+def test_engine_options_at_the_bench_shape(precision):
+    """One denoiser call at the bench shape under the engine's switches (didi_set_option): the attention fusions are exact, so
+    DIDI_OPT_FUSED_ATTN = 0 / 1 / 2 / 3 give IDENTICAL x0_hat.  The residual stream's remainder plane as bytes
+    (DIDI_OPT_LO8_RESIDUAL, default on) moves x0_hat by 4.7e-4 of its norm against the 16-bit plane, the hi-only stream
+    (DIDI_OPT_HI_RESIDUAL, opt-in, one-product calls only) by 1.3e-3.  These are distances between two ROUNDED computations (any
+    perturbation re-draws downstream fp16 roundings), not errors: against the reference the byte plane costs nothing measurable
+    and the hi-only stream doubles the error (test_cfg2_size_vs_reference_fixture, profiles/r03_lo8_fixture.log,
+    r03_hires_fixture.log) -- which is why the first is on and the second off."""
+    from didi_amd import _lib
+    from didi_amd.config import DiDiConfig
+    from didi_amd.model import DiDiSampler
+    from didi_amd.synthetic import synthetic_batch, synthetic_state_dict
+
+    cfg = DiDiConfig(diffusion_steps=2000)
+    sd = synthetic_state_dict(cfg, seed=1234)
+    B, C, S = 64, 64, 64
+    ids, mask = synthetic_batch(B, C, cfg.vocab, seed=0xBADB01)
+    g = torch.Generator().manual_seed(5)
+    x_t = torch.randn(B, S, cfg.dec_dim, generator=g)
+    tids = torch.randint(1, 2001, (B, 1), generator=g)
+    model = DiDiSampler(sd, cfg, device="cuda", precision=precision)
+
+    def call():
+        out, _ = model(encoder_input_ids=ids.cuda(), encoder_attention_mask=mask.cuda(), decoder_inputs_embeds=x_t.cuda(), time_ids=tids.cuda())
+        model.check_fault("engine options")
+        return out.clone()
+
+    defaults = {k: _lib.get_option(k) for k in ("FUSED_ATTN", "LO8_RESIDUAL", "HI_RESIDUAL")}
+    assert defaults == {"FUSED_ATTN": 3, "LO8_RESIDUAL": 1, "HI_RESIDUAL": 0}
+    try:
+        base = call()
+        for bits in (0, 1, 2):
+            _lib.set_option("FUSED_ATTN", bits)
+            assert torch.equal(call(), base), f"FUSED_ATTN={bits}"
+        _lib.set_option("FUSED_ATTN", 3)
+        _lib.set_option("LO8_RESIDUAL", 0)
+        full = call()
+        d8 = rel_l2(base, full)
+        _lib.set_option("HI_RESIDUAL", 1)
+        dh = rel_l2(call(), full)
+        print(f"\n[engine options {precision}] lo8 vs 16-bit remainder plane {d8:.2e}; hi-only vs 16-bit {dh:.2e}")
+        assert 0 < d8 <= 1e-3
+        if precision == "fp16":
+            assert 2 * d8 < dh <= 1e-2
+        else:
+            assert dh == 0.0  # two-product calls keep their remainder plane
+        assert _lib.lib.didi_set_option(_lib.OPTIONS["FUSED_ATTN"], 4) == -1
+    finally:
+        for k, v in defaults.items():
+            _lib.set_option(k, v)
+
+
 def test_config2_shape_euler_f10_full_loop_and_batch_invariance():
     """BASELINE configs[2] at its per-GPU shape: euler (= DDIM, s_churn 0), step_freq 10 (201 calls), 512 dialogs x 64 (M = 32 768
     rows), the default precision schedule, the whole loop.  The noise is injected from device memory (202 draws x 101 MB: it fits

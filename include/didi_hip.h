@@ -81,7 +81,7 @@ enum {
     DIDI_OPT_HI_RESIDUAL = 9,  /* 1: in DIDI_PREC_FP16 (one-product) decoder calls the residual stream between the fused projection +
                                   LayerNorm launches travels as its fp16 hi plane alone (12 bits; the remainder plane is neither written
                                   nor re-joined): half the bytes of those launches' epilogues.  0 (default): hi + lo everywhere */
-    DIDI_OPT_LO8_RESIDUAL = 10, /* 1 (default): in DIDI_PREC_FP16 / DIDI_PREC_FP16X2 decoder calls (no GEMM there multiplies an activation's
+    DIDI_OPT_LO8_RESIDUAL = 10, /* 1 (default): in DIDI_PREC_FP16 decoder calls (no GEMM there multiplies an activation's
                                   remainder plane) the remainder of the residual stream travels between the fused projection + LayerNorm
                                   launches as BYTES (didi_gemm_ln_lo8: hi + lo8, 14 bits and more): 3 instead of 4 bytes per value and
                                   direction in the launches whose epilogues those bytes bound.  0: 16-bit remainder plane everywhere */

@@ -230,11 +230,10 @@ def test_engine_options_at_the_bench_shape(precision):
         _lib.set_option("HI_RESIDUAL", 1)
         dh = rel_l2(call(), full)
         print(f"\n[engine options {precision}] lo8 vs 16-bit remainder plane {d8:.2e}; hi-only vs 16-bit {dh:.2e}")
-        assert 0 < d8 <= 1e-3
         if precision == "fp16":
-            assert 2 * d8 < dh <= 1e-2
+            assert 0 < d8 <= 1e-3 and 2 * d8 < dh <= 1e-2
         else:
-            assert dh == 0.0  # two-product calls keep their remainder plane
+            assert d8 == 0.0 and dh == 0.0  # two-product calls keep their 16-bit remainder plane
         assert _lib.lib.didi_set_option(_lib.OPTIONS["FUSED_ATTN"], 4) == -1
     finally:
         for k, v in defaults.items():

@@ -347,7 +347,20 @@ def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, resid
         z = torch.zeros((M, pad), dtype=torch.float32, device=dC.device)
         z[:, :N] = dC
         dc_hi, dc_lo = split(z, dtype=pd)
-    dA = gemm(dc_hi, dc_lo, wt_hi, wt_lo, precision=precision, out_f32=True, out_planes=False, residual=residual, fault=fault)[2] if need_dA else None
+    dA = None
+    if need_dA:
+        Kd = dc_hi.shape[1]  # the dgrad's contraction length (N, padded to 8)
+        K0 = Kd // 64 * 64
+        if Kd % 32 != 0 and K0 >= 1024:
+            # a long contraction that is not a multiple of the LDS-DMA kernels' K-step (the classifier: V = 8008) would fall to the
+            # register-staged kernel whole (1.1 ms at M = 16384); the aligned part goes through the fast kernel, the tail of < 64 columns
+            # adds on through the residual input
+            head = gemm(dc_hi[:, :K0], dc_lo[:, :K0], wt_hi[:, :K0], wt_lo[:, :K0], precision=precision, out_f32=True, out_planes=False,
+                        residual=residual, fault=fault)[2]
+            dA = gemm(dc_hi[:, K0:], dc_lo[:, K0:], wt_hi[:, K0:], wt_lo[:, K0:], precision=precision, out_f32=True, out_planes=False,
+                      residual=head, fault=fault)[2]
+        else:
+            dA = gemm(dc_hi, dc_lo, wt_hi, wt_lo, precision=precision, out_f32=True, out_planes=False, residual=residual, fault=fault)[2]
     if bias:
         dct_hi, dct_lo, db = transpose_split_colsum(dC, dtype=pd)  # [N, M8] + the bias gradient
     else:

@@ -136,6 +136,24 @@ def test_linear_backward_vs_fp64(M, N, K):
     assert rel_l2(db, dC.double().sum(0)) <= 1e-5
 
 
+@pytest.mark.parametrize("R,Cc", [(130, 72), (1000, 768), (2050, 8008), (61, 4), (64, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_transpose_split_vector_form(R, Cc, dtype):
+    """Column counts that are multiples of 4 take the kernel with 16-byte loads and 8-byte stores: same planes as the definition
+    (hi = the plane format's rounding of x^T, hi + lo = x^T to the remainder plane's precision, zero padding up to a multiple of
+    8 columns), and the fused column sums."""
+    from didi_amd import ops
+
+    x = torch.randn(R, Cc, generator=torch.Generator().manual_seed(R + Cc))
+    hi, lo = ops.transpose_split(x.cuda(), dtype=dtype)
+    ldo = (R + 7) // 8 * 8
+    assert tuple(hi.shape) == (Cc, ldo)
+    assert torch.equal(hi[:, :R].cpu(), x.T.to(dtype)) and float(ops.join(hi, lo)[:, R:].abs().max() if ldo > R else 0.0) == 0.0
+    assert rel_l2(ops.join(hi, lo)[:, :R], x.T) <= (2e-5 if dtype == torch.bfloat16 else 1e-6)
+    h2, l2, cs = ops.transpose_split_colsum(x.cuda(), dtype=dtype)
+    assert torch.equal(h2, hi) and torch.equal(l2, lo) and rel_l2(cs, x.double().sum(0)) <= 1e-6
+
+
 def test_transpose_split_and_colsum():
     from didi_amd import ops
 

@@ -188,6 +188,8 @@ SYMBOLS = [
     ("didi_transpose_split_colsum_bytes", C.c_size_t, [C.c_int, C.c_int]),
     ("didi_transpose_split_colsum", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_void_p]),
+    ("didi_split_both", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
     ("didi_act_backward", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("didi_axpby", C.c_int, [C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("didi_ce_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

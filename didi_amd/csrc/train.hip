@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256) transpose_split_kernel(const float* src, 
 // general form): thread t loads columns 4 (t & 15) .. + 3 of rows (t >> 4) + 16 j, and stores rows-of-the-source 4 (t & 15) .. + 3 as
 // four consecutive columns of output row (t >> 4) + 16 j.  2.9 -> ~4 TB/s of the pass's 8 bytes per element.
 __global__ void __launch_bounds__(256) transpose_split_kernel_v4(const float* src, int R, int C, int ldo, u16* hi, u16* lo, int f16,
-                                                                 float* partial) {
+                                                                 float* partial, u16* plain_hi = nullptr, u16* plain_lo = nullptr) {
     __shared__ float tile[64][65];
     __shared__ float red[16][64];
     if (f16) f16_saturate_mode();
@@ -304,7 +304,16 @@ __global__ void __launch_bounds__(256) transpose_split_kernel_v4(const float* sr
     for (int j = 0; j < 4; ++j) {
         const int i = tr + 16 * j, r = r0 + i, c = c0 + 4 * tq;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < R && c < C) v = *reinterpret_cast<const float4*>(src + (size_t)r * C + c);  // C % 4 == 0: c + 3 < C too
+        if (r < R && c < C) {
+            v = *reinterpret_cast<const float4*>(src + (size_t)r * C + c);  // C % 4 == 0: c + 3 < C too
+            if (plain_hi) {  // the un-transposed planes from the same read (the dgrad operand of linear_backward)
+                const float pv[4] = {v.x, v.y, v.z, v.w};
+                uint2 ph, pl;
+                split4(pv, ph, pl, f16);
+                *reinterpret_cast<uint2*>(plain_hi + (size_t)r * C + c) = ph;
+                if (plain_lo) *reinterpret_cast<uint2*>(plain_lo + (size_t)r * C + c) = pl;
+            }
+        }
         tile[i][4 * tq] = v.x; tile[i][4 * tq + 1] = v.y; tile[i][4 * tq + 2] = v.z; tile[i][4 * tq + 3] = v.w;
         cs[0] += v.x; cs[1] += v.y; cs[2] += v.z; cs[3] += v.w;
     }
@@ -362,6 +371,26 @@ extern "C" int didi_transpose_split_colsum(const float* src, int R, int C, int l
     DIDI_LAUNCH_CHECK();
     partial_rows_sum_kernel<<<cdiv(C, 64), 256, 0, st>>>(reinterpret_cast<const float*>(workspace), nb, C, C, colsum, nullptr);
     DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// transposed planes + un-transposed planes (+ column sums when colsum != NULL) of one fp32 matrix in ONE pass: what linear_backward
+// needs of dC (dgrad reads dC, wgrad dC^T, the bias gradient its column sums).  C % 4 == 0.
+extern "C" int didi_split_both(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
+                               int plane_format, float* colsum, void* workspace, void* stream) {
+    DIDI_CHECK_ARG(src && t_hi && p_hi && R > 0 && C > 0 && ldo >= R && ldo == (R + 7) / 8 * 8 && (!colsum || workspace));
+    DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
+    if (!transpose_v4_ok(src, C, ldo, t_hi, t_lo) || reinterpret_cast<uintptr_t>(p_hi) % 8 != 0 || reinterpret_cast<uintptr_t>(p_lo) % 8 != 0)
+        return DIDI_ERR_UNSUPPORTED;
+    const int nb = cdiv(ldo, 64);
+    hipStream_t st = as_stream(stream);
+    transpose_split_kernel_v4<<<dim3(cdiv(C, 64), nb), 256, 0, st>>>(src, R, C, ldo, t_hi, t_lo, plane_format == DIDI_FMT_FP16,
+                                                                      colsum ? reinterpret_cast<float*>(workspace) : nullptr, p_hi, p_lo);
+    DIDI_LAUNCH_CHECK();
+    if (colsum) {
+        partial_rows_sum_kernel<<<cdiv(C, 64), 256, 0, st>>>(reinterpret_cast<const float*>(workspace), nb, C, C, colsum, nullptr);
+        DIDI_LAUNCH_CHECK();
+    }
     return DIDI_OK;
 }
 

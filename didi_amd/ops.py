@@ -332,6 +332,22 @@ def transpose_split_colsum(x, dtype=torch.bfloat16):
     return hi, lo, out
 
 
+def split_both(x, dtype=torch.bfloat16, colsum=True):
+    """fp32 [R, C] -> (planes of x [R, C], planes of x^T [C, R8], column sums or None) in one pass (C % 4 == 0)."""
+    x = _f32c(x)
+    R, Cc = x.shape
+    ldo = (R + 7) // 8 * 8
+    p_hi = torch.empty((R, Cc), dtype=dtype, device=x.device)
+    p_lo = torch.empty_like(p_hi)
+    t_hi = torch.empty((Cc, ldo), dtype=dtype, device=x.device)
+    t_lo = torch.empty_like(t_hi)
+    out = torch.empty(Cc, dtype=torch.float32, device=x.device) if colsum else None
+    ws = torch.empty(lib.didi_transpose_split_colsum_bytes(R, Cc), dtype=torch.uint8, device=x.device) if colsum else None
+    _lib.check(lib.didi_split_both(x.data_ptr(), R, Cc, ldo, t_hi.data_ptr(), t_lo.data_ptr(), p_hi.data_ptr(), p_lo.data_ptr(), _fmt(dtype),
+                                   _lib.ptr(out), _lib.ptr(ws), _lib.current_stream()), "split_both")
+    return (p_hi, p_lo), (t_hi, t_lo), out
+
+
 def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, residual=None, fault=None):
     """Backward of C = A W^T + b (nn.Linear): dC [M,N], A [M,K], W [N,K] fp32 -> (dA [M,K] (+ residual), dW [N,K], db [N] or None).
     dgrad and wgrad are didi_gemm launches on transposed operand planes; db comes out of the pass that transposes dC.
@@ -340,7 +356,12 @@ def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, resid
     dC, A, W = _f32c(dC), _f32c(A), _f32c(W)
     M, N = dC.shape
     K = A.shape[1]
-    dc_hi, dc_lo = split(dC, dtype=pd)
+    one_pass = N % 8 == 0 and need_dA  # dC's planes, its transposed planes and its column sums from one read of dC
+    dct = None
+    if one_pass:
+        (dc_hi, dc_lo), dct, db1 = split_both(dC, dtype=pd, colsum=bias)
+    else:
+        dc_hi, dc_lo = split(dC, dtype=pd)
     wt_hi, wt_lo = transpose_split(W, dtype=pd)          # [K, N8]
     if wt_hi.shape[1] != N:  # K of this GEMM is N: the A operand must carry the same zero padding
         pad = wt_hi.shape[1]
@@ -361,7 +382,9 @@ def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, resid
                       residual=head, fault=fault)[2]
         else:
             dA = gemm(dc_hi, dc_lo, wt_hi, wt_lo, precision=precision, out_f32=True, out_planes=False, residual=residual, fault=fault)[2]
-    if bias:
+    if dct is not None:
+        (dct_hi, dct_lo), db = dct, (db1 if bias else None)
+    elif bias:
         dct_hi, dct_lo, db = transpose_split_colsum(dC, dtype=pd)  # [N, M8] + the bias gradient
     else:
         (dct_hi, dct_lo), db = transpose_split(dC, dtype=pd), None

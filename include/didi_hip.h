@@ -584,6 +584,12 @@ int didi_transpose_split(const float* src, int R, int C, int ldo, uint16_t* hi, 
 size_t didi_transpose_split_colsum_bytes(int R, int C);
 int didi_transpose_split_colsum(const float* src, int R, int C, int ldo, uint16_t* hi, uint16_t* lo, int plane_format, float* colsum,
                                 void* workspace, void* stream);
+/* Everything nn.Linear's backward needs of dC in ONE pass over it (torch autograd makes three: mm(dC, W), mm(dC^T, A), dC.sum(0)):
+ * the transposed planes t_* [C, ldo] (the weight-gradient operand), the un-transposed planes p_* [R, C] (the input-gradient
+ * operand) and, when colsum != NULL, the column sums (the bias gradient; workspace as above).  C % 4 == 0, else
+ * DIDI_ERR_UNSUPPORTED (callers then make the separate passes). */
+int didi_split_both(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
+                    int plane_format, float* colsum, void* workspace, void* stream);
 
 /* y = act(x) (fp32, nullable) + its split planes (nullable): the training forward keeps the pre-activation, so GELU is its own
  * pass there.  dx = dy * act'(.) for the two activations on the trained path: DIDI_ACT_GELU takes the PRE-activation (BertIntermediate,

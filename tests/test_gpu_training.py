@@ -154,6 +154,19 @@ def test_transpose_split_vector_form(R, Cc, dtype):
     assert torch.equal(h2, hi) and torch.equal(l2, lo) and rel_l2(cs, x.double().sum(0)) <= 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_split_both_equals_the_three_passes(dtype):
+    """didi_split_both: the planes of dC, of dC^T and the column sums from one read == split, transpose_split and colsum."""
+    from didi_amd import ops
+
+    x = torch.randn(1030, 776, generator=torch.Generator().manual_seed(3)).cuda()
+    (p_hi, p_lo), (t_hi, t_lo), cs = ops.split_both(x, dtype=dtype)
+    w_hi, w_lo = ops.split(x, dtype=dtype)
+    u_hi, u_lo, want_cs = ops.transpose_split_colsum(x, dtype=dtype)
+    assert torch.equal(p_hi, w_hi) and torch.equal(p_lo, w_lo) and torch.equal(t_hi, u_hi) and torch.equal(t_lo, u_lo) and torch.equal(cs, want_cs)
+    assert ops.split_both(x, dtype=dtype, colsum=False)[2] is None
+
+
 def test_transpose_split_and_colsum():
     from didi_amd import ops
 

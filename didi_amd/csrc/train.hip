@@ -634,6 +634,17 @@ __device__ __forceinline__ void mf_tn(const float* X, int ldx, int i0, const flo
 // its probability iff word (j & 3) of Philox4x32-10(counter = offset + (((b heads + h) Sq + i) Sk4 + j) / 4, key = seed) is
 // >= p 2^32, Sk4 = Sk rounded up to 4.  In LDS a dropped probability is stored NEGATED (probabilities are >= 0, -0.0 included):
 // products that want the dropped matrix clamp at zero, the softmax backward takes |P|; kept entries are scaled by 1 / (1 - p).
+// diagnostic build (-DDIDI_STAMPS): the backward, which has no use for p.O, writes s_memtime of wave 0 at its phase boundaries there
+// (tools/attn_train_stamps.py)
+#ifdef DIDI_STAMPS
+#define AT_STAMP(i)                                                                                              \
+    do {                                                                                                         \
+        if (BWD && p.O && threadIdx.x == 0)                                                                      \
+            reinterpret_cast<unsigned long long*>(p.O)[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define AT_STAMP(i) do {} while (0)
+#endif
 template <int NJ, bool BWD, bool MF = false>
 __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_args p) {
     extern __shared__ float sm[];
@@ -646,6 +657,38 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
     float* g = v + Sk * LD;                   // dO [Sq][LD] (BWD only)
     float* P = BWD ? g + Sq * LD : g;         // [Sq][LP]: scores -> probabilities (sign = dropout) -> dS
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    AT_STAMP(0);
+    if constexpr (MF) {
+        // D = 64: a row is 16 float4; every load of the workgroup's four operands is issued before the first LDS store, so the
+        // head's 64 KB arrive under ONE memory latency (the generic loop below waits per iteration: 16 us of a 30 us workgroup,
+        // tools/attn_train_stamps.py; with the loads batched the phase is the launch's bandwidth share, 7.6 us).  Tried on top and
+        // dropped: a workgroup walking three heads of its dialog with the next head's operands prefetched into registers
+        // (backward 236 -> 262 us, forward 81 -> 113 us: a third of the workgroups, and the compiler keeps the loads next to their use).
+        const int c = tid & 15, rb = tid >> 4;
+        float4 rq[6], rg[6], rk[NJ], rv[NJ];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (rb + 16 * j < Sq) {
+                rq[j] = ld4(p.Q + ((size_t)b * Sq + rb + 16 * j) * p.ldq + h * 64 + c * 4);
+                if (BWD) rg[j] = ld4(p.dO + ((size_t)b * Sq + rb + 16 * j) * p.ldo + h * 64 + c * 4);
+            }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            rk[j] = ld4(p.K + ((size_t)b * Sk + rb + 16 * j) * p.ldk + h * 64 + c * 4);
+            rv[j] = ld4(p.V + ((size_t)b * Sk + rb + 16 * j) * p.ldv + h * 64 + c * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (rb + 16 * j < Sq) {
+                *reinterpret_cast<float4*>(q + (rb + 16 * j) * LD + c * 4) = rq[j];
+                if (BWD) *reinterpret_cast<float4*>(g + (rb + 16 * j) * LD + c * 4) = rg[j];
+            }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            *reinterpret_cast<float4*>(k + (rb + 16 * j) * LD + c * 4) = rk[j];
+            *reinterpret_cast<float4*>(v + (rb + 16 * j) * LD + c * 4) = rv[j];
+        }
+    } else {
     for (int i = tid; i < Sq * L4; i += 256) {
         const int r = i / L4, c = i % L4;
         reinterpret_cast<float4*>(q)[i] = c < D_4 ? ld4(p.Q + ((size_t)b * Sq + r) * p.ldq + h * D + c * 4) : z4;
@@ -656,8 +699,10 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
         reinterpret_cast<float4*>(k)[i] = c < D_4 ? ld4(p.K + ((size_t)b * Sk + r) * p.ldk + h * D + c * 4) : z4;
         reinterpret_cast<float4*>(v)[i] = c < D_4 ? ld4(p.V + ((size_t)b * Sk + r) * p.ldv + h * D + c * 4) : z4;
     }
+    }
     for (int i = tid; i < Sq * (LP - Sk); i += 256) P[(i / (LP - Sk)) * LP + Sk + i % (LP - Sk)] = 0.f;  // padding columns stay zero
     __syncthreads();
+    AT_STAMP(1);  // operands in LDS
     constexpr float NEG = -3.4028234663852886e38f;
     const float scale = p.scale;
     const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
@@ -716,6 +761,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
             }
     }
     __syncthreads();
+    AT_STAMP(2);  // scores
     // ---- row softmax: four lanes per row
     for (int r = tid >> 2; r < Sq; r += 64) {
         float* row = P + r * LP;
@@ -730,6 +776,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
         for (int c = tid & 3; c < Sk; c += 4) row[c] *= inv;
     }
     __syncthreads();
+    AT_STAMP(3);  // softmax
     // ---- dropout: negate the dropped probabilities
     const bool drop = p.drop_p > 0.f;
     const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
@@ -794,6 +841,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
             }
         return;
     } else if constexpr (MF) {
+        AT_STAMP(4);  // dropout
         // ---- dV = dropout(P)^T dO: strips of 16 keys
         for (int j0 = 16 * wave; j0 < Sk; j0 += 64) {
             mf4 acc[4] = {mz, mz, mz, mz};
@@ -805,6 +853,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
                         p.dV[((size_t)b * Sk + j0 + 4 * lg + r4) * p.ldv + h * D + 16 * j + lr] = acc[j][r4] * inv_keep;
         }
         __syncthreads();
+        AT_STAMP(5);  // dV
         // ---- dP = (dO V^T) o mask / keep; D_i = sum_c |P| dP (a wave owns whole rows: in-lane over the column tiles, then over the
         // 16 lanes of a row group); dS = |P| (dP - D) scale, back into P
         for (int i0 = 16 * wave; i0 < Sq; i0 += 64) {
@@ -835,6 +884,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
                     for (int r4 = 0; r4 < 4; ++r4) P[(i0 + 4 * lg + r4) * LP + 16 * j + lr] = pv[j][r4] * (acc[j][r4] - dr[r4]) * scale;
         }
         __syncthreads();
+        AT_STAMP(6);  // dP -> dS
         // ---- dQ = dS K
         for (int i0 = 16 * wave; i0 < Sq; i0 += 64) {
             mf4 acc[4] = {mz, mz, mz, mz};
@@ -845,6 +895,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
                     for (int r4 = 0; r4 < 4; ++r4)
                         p.dQ[((size_t)b * Sq + i0 + 4 * lg + r4) * p.ldq + h * D + 16 * j + lr] = acc[j][r4];
         }
+        AT_STAMP(7);  // dQ
         // ---- dK = dS^T Q
         for (int j0 = 16 * wave; j0 < Sk; j0 += 64) {
             mf4 acc[4] = {mz, mz, mz, mz};
@@ -855,6 +906,11 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
                     for (int r4 = 0; r4 < 4; ++r4)
                         p.dK[((size_t)b * Sk + j0 + 4 * lg + r4) * p.ldk + h * D + 16 * j + lr] = acc[j][r4];
         }
+        AT_STAMP(8);  // dK issued
+#ifdef DIDI_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        AT_STAMP(9);  // drained
     } else {
         // ---- dV = dropout(P)^T dO
         for (int m0 = 0; m0 < Sk4; m0 += 64) {

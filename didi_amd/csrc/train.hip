@@ -194,6 +194,13 @@ __global__ void __launch_bounds__(256) partial_rows_sum_kernel(const float* part
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (n < total) {
         int b = wave;
+        for (; b + 60 < nblk; b += 64) {  // 16 independent loads in flight: the kernel is a chain of memory latencies (12 workgroups at N = 768)
+            float t_[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t_[u] = partial[(size_t)(b + 4 * u) * stride + n];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { a0 += t_[u]; a1 += t_[u + 1]; a2 += t_[u + 2]; a3 += t_[u + 3]; }
+        }
         for (; b + 12 < nblk; b += 16) {
             a0 += partial[(size_t)b * stride + n];
             a1 += partial[(size_t)(b + 4) * stride + n];

@@ -266,6 +266,10 @@ class DiDiTrainer:
         if t is None:
             t = torch.randint(1, T + 1, size=(B, 1), device=dev)
         t = t.to(dev)
+        # the two host scalars of the step (loss weights are kernel arguments): read HERE, where they depend on the inputs only and the
+        # stream is still empty, instead of after the forward, where the read drained a queue of ~700 launches
+        n_tok_f = float(tmask.sum().item())
+        pf = float((t.view(-1) == 1).float().mean().item())
         sigma = self.sigmas[t.view(-1)]
         s_b = (sigma * self.noise_factor ** 2).contiguous()
         c_b = (1.0 / torch.sqrt(sigma * sigma + 1.0)).contiguous()
@@ -348,8 +352,6 @@ class DiDiTrainer:
         mse = p * per[:, 0].mean() + (1.0 - p) * per[:, 1].mean()
         sigma_T = self.sigmas[-1]
         t_T = sums[:, 2].sum() / (sigma_T * sigma_T + 1.0) / float(B * S * H)
-        n_tok = tmask.sum()
-        n_tok_f = float(n_tok.item())
         # Loss scale of the backward: every loss weight carries a 1 / (B S H) or 1 / tokens, which puts the gradients of the
         # activations near fp16's subnormals.  fp16-plane precisions run the backward on `ls` x the loss (a power of two, so
         # exact) and the parameter gradients are scaled back at the end; bf16 planes have fp32's exponent range (ls = 1).
@@ -383,7 +385,6 @@ class DiDiTrainer:
         del dlg
         loss = mse + ce if self.anchor_loss else mse + ce + t_T
         # ---- backward
-        pf = float(p.item())
         w_emb, w_x0 = ls * 2.0 * pf / (B * S * H), ls * 2.0 * (1.0 - pf) / (B * S * H)
         w_T = 0.0 if self.anchor_loss else ls * 2.0 / ((float(sigma_T) ** 2 + 1.0) * B * S * H)
         dh = ops.train_mse_backward(x_0_hat, emb, x_0, tmask, w_emb, w_x0).view(M, H)

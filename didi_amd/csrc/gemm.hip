@@ -1385,23 +1385,41 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             uint4 rh[2][3], rl[2][3];
+            // the three forms of the remainder plane (bytes, 16 bit, none) are three straight-line runs of loads: a branch PER load made
+            // hipcc put s_waitcnt vmcnt(0) between the loads (registers shared across the paths), one memory latency each
+            const int lo_form = (F16 && (p.lo8 & 1)) ? 2 : p.R_lo ? 1 : 0;
+            auto r_at = [&](int mj, int k) {
+                const int m = min(m0 + wm * 64 + (half * 2 + mj) * 16 + lr, p.M - 1);
+                return (size_t)m * p.ldr + (n0 + wn * 96 + 32 * k + 8 * lg);
+            };
+            if (lo_form == 2) {
 #pragma unroll
-            for (int mj = 0; mj < 2; ++mj)
+                for (int mj = 0; mj < 2; ++mj)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int m = min(m0 + wm * 64 + (half * 2 + mj) * 16 + lr, p.M - 1);
-                    const int n = n0 + wn * 96 + 32 * k + 8 * lg;
-                    rh[mj][k] = *reinterpret_cast<const uint4*>(p.R_hi + (size_t)m * p.ldr + n);
-                    rl[mj][k] = uint4{0, 0, 0, 0};
-                    if constexpr (F16) {
-                        if (p.lo8 & 1) {  // byte plane: 8 B per lane; the factor 1 / 256 rides in the add below
-                            const uint2 b8 = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.R_lo) + (size_t)m * p.ldr + n);
-                            rl[mj][k] = make_uint4(b8.x, b8.y, 0, 0);
-                            continue;
-                        }
+                    for (int k = 0; k < 3; ++k) {
+                        const size_t o = r_at(mj, k);
+                        rh[mj][k] = *reinterpret_cast<const uint4*>(p.R_hi + o);
+                        const uint2 b8 = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.R_lo) + o);  // 8 B per lane; x 1 / 256 below
+                        rl[mj][k] = make_uint4(b8.x, b8.y, 0, 0);
                     }
-                    if (p.R_lo) rl[mj][k] = *reinterpret_cast<const uint4*>(p.R_lo + (size_t)m * p.ldr + n);  // null: the residual is its hi plane
-                }
+            } else if (lo_form == 1) {
+#pragma unroll
+                for (int mj = 0; mj < 2; ++mj)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const size_t o = r_at(mj, k);
+                        rh[mj][k] = *reinterpret_cast<const uint4*>(p.R_hi + o);
+                        rl[mj][k] = *reinterpret_cast<const uint4*>(p.R_lo + o);
+                    }
+            } else {  // the residual is its hi plane
+#pragma unroll
+                for (int mj = 0; mj < 2; ++mj)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        rh[mj][k] = *reinterpret_cast<const uint4*>(p.R_hi + r_at(mj, k));
+                        rl[mj][k] = uint4{0, 0, 0, 0};
+                    }
+            }
             const float rl_scale = F16 && (p.lo8 & 1) ? 1.0f / DIDI_LO8_SCALE : 1.0f;
 #pragma unroll
             for (int mj = 0; mj < 2; ++mj) {

@@ -230,7 +230,10 @@ extern "C" int didi_mul_split(const float* a, const float* b, size_t n, uint16_t
 // ------------------------------------------------------------------ sampler step + decoder prologue
 // bytes per row (H fp32 = 4H): DDPM reads x0 (4H) [+ eps 4H when injected], writes planes (4H)
 // [+ x_t 4H when traced]; the reference makes 3 elementwise passes + gather + add + LN passes.
-template <int MAXV>
+// MODE is a template parameter and every load of a row is issued before the first use: with the mode as a run-time branch per
+// 16-byte chunk hipcc placed the x0 load, the Philox draws, the time / token-type / position loads of each chunk one after the
+// other with s_waitcnt vmcnt(0) between them -- six memory latencies in a row per wave (28.6 us per call at 16384 x 768).
+template <int MAXV, int MODE>
 __global__ void __launch_bounds__(256) step_embed_ln_kernel(didi_step_args a) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -239,33 +242,47 @@ __global__ void __launch_bounds__(256) step_embed_ln_kernel(didi_step_args a) {
     const size_t row_off = (size_t)m * H;
     const int s = m % a.S;
     const int t = a.time_idx ? a.time_idx[m / a.S] : a.t;
-    const bool draw = (a.E == nullptr) && (a.ce != 0.f) && (a.mode != DIDI_STEP_NONE);
+    constexpr bool RD_X = MODE == DIDI_STEP_EULER || MODE == DIDI_STEP_NONE, RD_X0 = MODE == DIDI_STEP_DDPM || MODE == DIDI_STEP_EULER;
+    const bool inj = a.E != nullptr && MODE != DIDI_STEP_NONE, emb = a.h_hi != nullptr;
+    const bool draw = !inj && (a.ce != 0.f) && MODE != DIDI_STEP_NONE;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 qx[MAXV], qx0[MAXV], qe[MAXV], qte[MAXV], qtk[MAXV], qps[MAXV];
+    int cc[MAXV];  // chunks past the row read chunk 0 instead (never used): no branch between the loads
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        cc[j] = (lane + 64 * j) * 4 < H ? lane + 64 * j : 0;
+        qx[j] = qx0[j] = qe[j] = qte[j] = qtk[j] = qps[j] = z4;
+        if constexpr (RD_X) qx[j] = reinterpret_cast<const float4*>(a.X + row_off)[cc[j]];
+        if constexpr (RD_X0) qx0[j] = reinterpret_cast<const float4*>(a.X0 + row_off)[cc[j]];
+    }
+    if (inj) {
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) qe[j] = reinterpret_cast<const float4*>(a.E + row_off)[cc[j]];
+    }
+    if (emb) {
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            qte[j] = reinterpret_cast<const float4*>(a.time_embeds + (size_t)t * H)[cc[j]];
+            qtk[j] = reinterpret_cast<const float4*>(a.tok_type0)[cc[j]];
+            qps[j] = reinterpret_cast<const float4*>(a.pos_emb + (size_t)s * H)[cc[j]];
+        }
+    }
     float v[MAXV][4];
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
         const int c = lane + 64 * j;
+        v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
         if (c * 4 < H) {
-            float x[4] = {0.f, 0.f, 0.f, 0.f}, x0[4] = {0.f, 0.f, 0.f, 0.f}, e[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.mode == DIDI_STEP_EULER || a.mode == DIDI_STEP_NONE) {
-                const float4 q = reinterpret_cast<const float4*>(a.X + row_off)[c];
-                x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
-            }
-            if (a.mode == DIDI_STEP_DDPM || a.mode == DIDI_STEP_EULER) {
-                const float4 q = reinterpret_cast<const float4*>(a.X0 + row_off)[c];
-                x0[0] = q.x; x0[1] = q.y; x0[2] = q.z; x0[3] = q.w;
-            }
-            if (a.E && a.mode != DIDI_STEP_NONE) {
-                const float4 q = reinterpret_cast<const float4*>(a.E + row_off)[c];
-                e[0] = q.x; e[1] = q.y; e[2] = q.z; e[3] = q.w;
-            } else if (draw) {
-                philox_normal4(a.offset + (row_off / 4 + c), a.seed, e);
-            }
+            float x[4] = {qx[j].x, qx[j].y, qx[j].z, qx[j].w};
+            const float x0[4] = {qx0[j].x, qx0[j].y, qx0[j].z, qx0[j].w};
+            float e[4] = {qe[j].x, qe[j].y, qe[j].z, qe[j].w};
+            if (draw) philox_normal4(a.offset + (row_off / 4 + c), a.seed, e);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float r;
-                if (a.mode == DIDI_STEP_INIT) r = a.ce * e[k];
-                else if (a.mode == DIDI_STEP_DDPM) r = a.cx0 * x0[k] + a.ce * e[k];
-                else if (a.mode == DIDI_STEP_EULER) r = (x[k] + (x[k] - x0[k]) * a.ratio) + a.ce * e[k];
+                if constexpr (MODE == DIDI_STEP_INIT) r = a.ce * e[k];
+                else if constexpr (MODE == DIDI_STEP_DDPM) r = a.cx0 * x0[k] + a.ce * e[k];
+                else if constexpr (MODE == DIDI_STEP_EULER) r = (x[k] + (x[k] - x0[k]) * a.ratio) + a.ce * e[k];
                 else r = x[k];
                 x[k] = r;
             }
@@ -273,22 +290,25 @@ __global__ void __launch_bounds__(256) step_embed_ln_kernel(didi_step_args a) {
             if (a.xin_out)
                 *reinterpret_cast<float4*>(a.xin_out + row_off + (size_t)c * 4) =
                     make_float4(a.cin * x[0], a.cin * x[1], a.cin * x[2], a.cin * x[3]);
-            if (a.h_hi) {
-                const float4 te = reinterpret_cast<const float4*>(a.time_embeds + (size_t)t * H)[c];
-                const float4 tk = reinterpret_cast<const float4*>(a.tok_type0)[c];
-                const float4 ps = reinterpret_cast<const float4*>(a.pos_emb + (size_t)s * H)[c];
-                // (x + time) + token_type + position: the reference's association order
-                v[j][0] = ((a.cin * x[0] + te.x) + tk.x) + ps.x;
-                v[j][1] = ((a.cin * x[1] + te.y) + tk.y) + ps.y;
-                v[j][2] = ((a.cin * x[2] + te.z) + tk.z) + ps.z;
-                v[j][3] = ((a.cin * x[3] + te.w) + tk.w) + ps.w;
-            }
-        } else {
-            v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+            // (x + time) + token_type + position: the reference's association order
+            v[j][0] = ((a.cin * x[0] + qte[j].x) + qtk[j].x) + qps[j].x;
+            v[j][1] = ((a.cin * x[1] + qte[j].y) + qtk[j].y) + qps[j].y;
+            v[j][2] = ((a.cin * x[2] + qte[j].z) + qtk[j].z) + qps[j].z;
+            v[j][3] = ((a.cin * x[3] + qte[j].w) + qtk[j].w) + qps[j].w;
         }
     }
-    if (a.h_hi) ln_row_store<MAXV>(v, lane, H, row_off, a.ln_gamma, a.ln_beta, a.ln_eps, a.h_hi, a.h_lo, nullptr,
-                                  a.plane_format == DIDI_FMT_FP16, a.act_dither);
+    if (emb) ln_row_store<MAXV>(v, lane, H, row_off, a.ln_gamma, a.ln_beta, a.ln_eps, a.h_hi, a.h_lo, nullptr,
+                               a.plane_format == DIDI_FMT_FP16, a.act_dither);
+}
+
+template <int MAXV>
+static void launch_step(const didi_step_args* a, int grid, hipStream_t st) {
+    switch (a->mode) {
+        case DIDI_STEP_INIT: step_embed_ln_kernel<MAXV, DIDI_STEP_INIT><<<grid, 256, 0, st>>>(*a); break;
+        case DIDI_STEP_DDPM: step_embed_ln_kernel<MAXV, DIDI_STEP_DDPM><<<grid, 256, 0, st>>>(*a); break;
+        case DIDI_STEP_EULER: step_embed_ln_kernel<MAXV, DIDI_STEP_EULER><<<grid, 256, 0, st>>>(*a); break;
+        default: step_embed_ln_kernel<MAXV, DIDI_STEP_NONE><<<grid, 256, 0, st>>>(*a); break;
+    }
 }
 
 extern "C" int didi_step_embed_ln(const didi_step_args* a, void* stream) {
@@ -304,10 +324,10 @@ extern "C" int didi_step_embed_ln(const didi_step_args* a, void* stream) {
     if (a->M == 0) return DIDI_OK;
     const int grid = cdiv(a->M, 4);
     hipStream_t st = as_stream(stream);
-    if (a->H <= 256) step_embed_ln_kernel<1><<<grid, 256, 0, st>>>(*a);
-    else if (a->H <= 768) step_embed_ln_kernel<3><<<grid, 256, 0, st>>>(*a);
-    else if (a->H <= 1280) step_embed_ln_kernel<5><<<grid, 256, 0, st>>>(*a);
-    else step_embed_ln_kernel<8><<<grid, 256, 0, st>>>(*a);
+    if (a->H <= 256) launch_step<1>(a, grid, st);
+    else if (a->H <= 768) launch_step<3>(a, grid, st);
+    else if (a->H <= 1280) launch_step<5>(a, grid, st);
+    else launch_step<8>(a, grid, st);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

@@ -718,6 +718,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #ifdef DIDI_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();  // the wave's first instructions (slot 13, 100 MHz)
 #endif
+    // every kernel argument the prologue and the loop need, fetched in ONE batch of scalar loads: left to itself hipcc loads them where
+    // they are first used, four groups each behind its own s_waitcnt lgkmcnt(0) -- four scalar-memory latencies before the first DMA
+    asm volatile("" ::"s"(p.A_hi), "s"(p.A_lo), "s"(p.W_hi), "s"(p.W_lo), "s"(p.lda), "s"(p.ldw), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.tiles_n),
+                 "s"(p.bias), "s"(p.act), "s"(p.C_hi), "s"(p.C_lo), "s"(p.C_f32), "s"(p.ldc), "s"(p.k_split), "s"(p.dither));
+    if constexpr (LN)
+        asm volatile("" ::"s"(p.R_hi), "s"(p.R_lo), "s"(p.ldr), "s"(p.ln_gamma), "s"(p.ln_beta), "s"(p.ln_stats), "s"(p.ln_epoch), "s"(p.ln_eps), "s"(p.lo8),
+                     "s"(p.fault));
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * BBN;
     if constexpr (!LN && !AMAX && ATTN == 0) {

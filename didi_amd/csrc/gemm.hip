@@ -1506,19 +1506,21 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
             float sj[4], qj[4];
             bool complete = false;
             for (int spins = 0; spins < (1 << 20); ++spins) {
-                bool ok = true;
+                // the eight granules of the row (tiles_n == 4 in this form) as eight loads in flight, then the tags: a branch or a
+                // short-circuit between the loads costs one L2 round trip per pair
+                unsigned long long x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    x[j] = __hip_atomic_load(gran + ((size_t)(j >> 1) * 256 + tid) * 2 + (j & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned bad = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bad |= (unsigned)(x[j] >> 32) ^ p.ln_epoch;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    sj[j] = 0.f; qj[j] = 0.f;
-                    if (j < p.tiles_n) {
-                        const unsigned long long x0 = __hip_atomic_load(gran + ((size_t)j * 256 + tid) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long x1 = __hip_atomic_load(gran + ((size_t)j * 256 + tid) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = ok && (unsigned)(x0 >> 32) == p.ln_epoch && (unsigned)(x1 >> 32) == p.ln_epoch;
-                        sj[j] = __builtin_bit_cast(float, (unsigned)x0);
-                        qj[j] = __builtin_bit_cast(float, (unsigned)x1);
-                    }
+                    sj[j] = __builtin_bit_cast(float, (unsigned)x[2 * j]);
+                    qj[j] = __builtin_bit_cast(float, (unsigned)x[2 * j + 1]);
                 }
-                if (__all(ok)) { complete = true; break; }
+                if (__all(bad == 0)) { complete = true; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             // combine: mean, then M2 = sum_j [M2_j + n_j (mean_j - mean)^2]

@@ -1456,15 +1456,24 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         }
         PP_STAMP(3);  // bias + residual added: both halves' residual planes have arrived
         // 2. local sums over this workgroup's 192 columns
-        float ml[4];
+        // (the four row groups' cross-lane steps are issued together: one LDS-crossbar round trip per step, not one per row group)
+        float ml[4], ts[4], tu[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-            float t = 0.f;
+            ts[mi] = 0.f;
 #pragma unroll
-            for (int ni = 0; ni < 6; ++ni) t += (acc[ni][mi][0] + acc[ni][mi][1]) + (acc[ni][mi][2] + acc[ni][mi][3]);
-            t += __shfl_xor(t, 16, 64);
-            t += __shfl_xor(t, 32, 64);
-            if (lg == 0) red[wn * 256 + wm * 64 + mi * 16 + lr] = t;
+            for (int ni = 0; ni < 6; ++ni) ts[mi] += (acc[ni][mi][0] + acc[ni][mi][1]) + (acc[ni][mi][2] + acc[ni][mi][3]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) tu[mi] = __shfl_xor(ts[mi], 16, 64);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) ts[mi] += tu[mi];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) tu[mi] = __shfl_xor(ts[mi], 32, 64);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            ts[mi] += tu[mi];
+            if (lg == 0) red[wn * 256 + wm * 64 + mi * 16 + lr] = ts[mi];
         }
         __syncthreads();
 #pragma unroll
@@ -1483,9 +1492,18 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
                     const float d = acc[ni][mi][i] - ml[mi];
                     q += d * d;
                 }
-            q += __shfl_xor(q, 16, 64);
-            q += __shfl_xor(q, 32, 64);
-            if (lg == 0) red2[wn * 256 + wm * 64 + mi * 16 + lr] = q;
+            ts[mi] = q;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) tu[mi] = __shfl_xor(ts[mi], 16, 64);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) ts[mi] += tu[mi];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) tu[mi] = __shfl_xor(ts[mi], 32, 64);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            ts[mi] += tu[mi];
+            if (lg == 0) red2[wn * 256 + wm * 64 + mi * 16 + lr] = ts[mi];
         }
         __syncthreads();
         PP_STAMP(4);  // local statistics done

@@ -24,7 +24,7 @@ ACT_NONE, ACT_GELU, ACT_TANH, ACT_RELU, ACT_GELU_NEW = 0, 1, 2, 3, 4
 STEP_NONE, STEP_INIT, STEP_DDPM, STEP_EULER = 0, 1, 2, 3
 ERR_FAULT = -5
 FAULT_LN_EXCHANGE, FAULT_FP16_RANGE = 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 # didi_set_option keys (tuning switches for A/B runs; defaults = production path)
 OPTIONS = {"GEMM_LN": 0, "GEMM_SMALL": 1, "GEMM_BIG": 2, "GEMM_PP": 3, "GEMM_MT": 4, "BIG_MIN_M": 5, "SMALL_MAX_M": 6, "X2_GEMMS": 7, "FUSED_ATTN": 8, "HI_RESIDUAL": 9, "LO8_RESIDUAL": 10}
 
@@ -188,6 +188,9 @@ SYMBOLS = [
     ("didi_transpose_split_colsum_bytes", C.c_size_t, [C.c_int, C.c_int]),
     ("didi_transpose_split_colsum", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_void_p]),
+    ("didi_gemm_wgrad_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("didi_gemm_wgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
     ("didi_split_both", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     ("didi_act_backward", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -707,9 +707,17 @@ __device__ __forceinline__ bf16x8 lds_tr8(const char* p0, const char* p1) {
 // each wave runs two 16-query blocks of one dialog exactly as attn_kernel does.  The [M, 3H] projection planes (75 MB written
 // and 75 MB read back per layer at the benchmark shape) and the attention launch disappear; the outputs are bit-identical to
 // didi_gemm + didi_attention (same conversions, same MFMA and summation order).
-template <int NPASS, bool F16, bool LN, bool AMAX = false, int ATTN = 0>
+// TN: the weight-gradient form (didi_gemm_wgrad): dW[n][k] = sum_m dC[m][n] A[m][k] reads BOTH operands as they lie in memory, the
+// contraction index m being the ROW index of the sources (A_* = dC planes [K][lda], W_* = activation planes [K][ldw]; p.M / p.N
+// are the output's rows / columns, p.K the number of source rows).  A K-tile is then [32 source rows][256 or 192 columns] in LDS
+// (16-byte pieces along the columns: coalesced, no transposed copy of either operand is ever made), and the MFMA fragments come
+// out of it through ds_read_b64_tr_b16, which hands lane lr column lr of a 4 x 16 block addressed row-wise by the 16 lanes.
+// Lane (lr, lg)'s eight contraction indices are then {4 lg .. 4 lg + 3, 16 + 4 lg ..} in BOTH fragments instead of 8 lg .. 8 lg + 7:
+// a permutation of the sum, nothing else.  Raw fp32 sums out (split-K partials), accumulator tile ni = 16 consecutive columns.
+template <int NPASS, bool F16, bool LN, bool AMAX = false, int ATTN = 0, bool TN = false>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     using G = BigGeom<4>;
+    static_assert(!TN || (NPASS != 1 && !LN && !AMAX && ATTN == 0), "the transposed-source form: two- / three-product split-K launches only");
     constexpr int BKK = NPASS == 1 ? 64 : 32;
     constexpr int CPR = BKK * 2 / 16, RPI = 64 / CPR;   // 16-byte chunks per LDS row, rows per DMA piece
     constexpr int NYP = NPASS == 2 ? 4 : 8;             // activation pieces per wave of group Y (fp16x2 stages no A_lo tile)
@@ -730,7 +738,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     if constexpr (!LN && !AMAX && ATTN == 0) {
         if (p.k_split) {  // split-K form (didi_gemm_small on weight-gradient shapes): K columns [y k_split, ...), raw partial sums
             const int k0 = blockIdx.y * p.k_split;
-            p.A_hi += k0; p.A_lo += k0; p.W_hi += k0; p.W_lo += k0;
+            const size_t ka = TN ? (size_t)k0 * p.lda : k0, kw = TN ? (size_t)k0 * p.ldw : k0;
+            p.A_hi += ka; p.A_lo += ka; p.W_hi += kw; p.W_lo += kw;
             p.K = min(p.k_split, p.K - k0);
             p.C_f32 += (size_t)blockIdx.y * p.M * p.ldc;
         }
@@ -761,6 +770,26 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         } else {
             base = grp ? p.A_hi : p.W_hi; row = q * RPI;
         }
+        if constexpr (TN) {
+            // piece q (1 KiB of LDS, lane l at byte 16 l) of a [32][256] activation-side or [32][192] weight-side K-tile: LDS row kk,
+            // 16-byte position c_ in it.  The source chunk that goes there: activation side c_ ^ 2 (kk & 7), weight side the 32-byte
+            // pair rotated by kk >> 1 (mod 12) -- the eight rows one ds_read_b64_tr_b16 touches per half wave then fall on eight
+            // different bank groups (row strides 512 B and 384 B)
+            int kk, c;
+            if (grp) { kk = 2 * (q & 15) + (lane >> 5); c = (lane & 31) ^ ((kk & 7) << 1); }
+            else {
+                const int idx = (q < 12 ? q : q - 12) * 64 + lane;
+                kk = idx / 24;
+                const int c_ = idx - kk * 24;
+                int pr = (c_ >> 1) - ((kk >> 1) % 12);
+                pr += pr < 0 ? 12 : 0;
+                c = 2 * pr + (c_ & 1);
+            }
+            const int lim = grp ? p.M : p.N, o0 = grp ? m0 : n0;
+            src[j] = base + (size_t)kk * (grp ? p.lda : p.ldw) + min(o0 + 8 * c, lim - 8);
+            qoff[j] = (grp ? 0 : W_OFF) + q * 1024;
+            continue;
+        }
         row += lane / CPR;
         const int slot = lane % CPR;
         const int g = NPASS != 1 ? (slot ^ ((0 - (row >> 2)) & 3)) : (slot ^ (row & 7));
@@ -774,17 +803,46 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         qoff[j] = (grp ? 0 : W_OFF) + q * 1024;
     }
     const int nt = p.K / BKK;
-#define PP_ISSUE(T, BUF, N)                                                                        \
-    do {                                                                                           \
-        char* st_ = smem + (BUF) * STAGE;                                                          \
-        _Pragma("unroll") for (int j = 0; j < (N); ++j) glds16(src[j] + (T) * BKK, st_ + qoff[j]); \
+    const size_t kstep = TN ? (size_t)BKK * (grp ? p.lda : p.ldw) : BKK;  // elements from one K-tile to the next
+#define PP_ISSUE(T, BUF, N)                                                                          \
+    do {                                                                                             \
+        char* st_ = smem + (BUF) * STAGE;                                                            \
+        _Pragma("unroll") for (int j = 0; j < (N); ++j) {                                            \
+            if constexpr (TN) glds16_raw(src[j] + (T) * kstep, st_ + qoff[j]); /* no compiler-made vmcnt(0) before the transposing reads */ \
+            else glds16(src[j] + (T) * kstep, st_ + qoff[j]);                                        \
+        }                                                                                            \
     } while (0)
+    // TN: byte offsets of this lane's transposing reads.  The lane addresses row 4 lg + (lr >> 2) (and 16 below it) of the K-tile,
+    // columns 4 (lr & 3) .. + 3 of the fragment's 16
+    int ta[4], tw0[6], tw1[6];
+    if constexpr (TN) {
+        const int kk = 4 * lg + (lr >> 2), sub = 8 * (lr & 1), hc = (lr & 3) >> 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ta[i] = kk * 512 + (((wm * 8 + i * 2 + hc) ^ ((kk & 7) << 1)) << 4) + sub;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            int p0 = wn * 6 + i + (kk >> 1), p1 = p0 + 8;  // kk < 16: kk >> 1 < 8, ((kk + 16) >> 1) % 12 = ((kk >> 1) + 8) % 12
+            p0 -= p0 >= 12 ? 12 : 0;
+            p1 -= p1 >= 24 ? 24 : p1 >= 12 ? 12 : 0;
+            tw0[i] = kk * 384 + p0 * 32 + hc * 16 + sub;
+            tw1[i] = (kk + 16) * 384 + p1 * 32 + hc * 16 + sub;
+        }
+    }
 
     // fragments: NPASS 1: fw[ks*6 + ni], fa[ks*4 + mi]; NPASS 3: fw[ni] hi, fw[6 + ni] lo, fa[mi] hi, fa[4 + mi] lo (NPASS 2: no fa lo)
     bf16x8 fw[12], fa[8];
 #define PP_READ(ST)                                                                                        \
     do {                                                                                                   \
-        if constexpr (NPASS != 1) {                                                                        \
+        if constexpr (TN) {                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                \
+                fw[i] = lds_tr8((ST) + W_OFF + tw0[i], (ST) + W_OFF + tw1[i]);                             \
+                fw[6 + i] = lds_tr8((ST) + W_OFF + LO_W + tw0[i], (ST) + W_OFF + LO_W + tw1[i]);           \
+            }                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+                fa[i] = lds_tr8((ST) + ta[i], (ST) + ta[i] + 8192);                                        \
+                if constexpr (NPASS == 3) fa[4 + i] = lds_tr8((ST) + LO_A + ta[i], (ST) + LO_A + ta[i] + 8192); \
+            }                                                                                              \
+        } else if constexpr (NPASS != 1) {                                                                 \
             _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                \
                 const int wo = swz64(wn * 96 + i * 16 + lr, lg);                                           \
                 fw[i] = *reinterpret_cast<const bf16x8*>((ST) + W_OFF + wo);                               \
@@ -828,7 +886,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 
     // one-product GELU launches: the 8-KiB table rides behind the stages, one LDS-DMA piece per wave,
     // issued first so that every later counted wait covers it
-    const bool use_lut = NPASS != 3 && p.act == DIDI_ACT_GELU;
+    const bool use_lut = !TN && NPASS != 3 && p.act == DIDI_ACT_GELU;
     if (use_lut) glds16(reinterpret_cast<const u16*>(didi_gelu_table) + wave * 512 + lane * 8, smem + 2 * STAGE + wave * 1024);
     // the tile's 192 bias values ride along too (one 768-byte piece, wave 0): the epilogue then reads them from LDS instead of
     // opening with a dependent global load
@@ -880,7 +938,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         if (wave == 0 && lane < 48)
             glds16(reinterpret_cast<const u16*>(p.bias + ((4 * lane) >> 6) * (p.N / 3) + (tile % p.tiles_n) * 64 + ((4 * lane) & 63)),
                    reinterpret_cast<char*>(bias_lds));
-    } else if (!AMAX && p.bias && wave == 0 && lane < 48 && n0 + 4 * lane < p.N)
+    } else if (!AMAX && !TN && p.bias && wave == 0 && lane < 48 && n0 + 4 * lane < p.N)
         glds16(reinterpret_cast<const u16*>(p.bias + n0 + 4 * lane), reinterpret_cast<char*>(bias_lds));
     float* gamma_lds = bias_lds + 256;  // LayerNorm variant: gamma and beta of the tile's columns, waves 1 and 2
     float* beta_lds = bias_lds + 512;
@@ -950,6 +1008,19 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #undef PP_READ
 #undef PP_MFMA
     PP_STAMP(2);  // K-loop done (this wave group)
+    if constexpr (TN) {  // raw sums: acc[ni][mi][r] = C[m0 + 64 wm + 16 mi + lr][n0 + 96 wn + 16 ni + 4 lg + r]
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 64 + mi * 16 + lr;
+#pragma unroll
+            for (int ni = 0; ni < 6; ++ni) {
+                const int n = n0 + wn * 96 + ni * 16 + 4 * lg;
+                if (m < p.M && n < p.N)  // N % 8 == 0: n + 3 < N too
+                    *reinterpret_cast<float4*>(p.C_f32 + (size_t)m * p.ldc + n) = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+            }
+        }
+        return;
+    }
     if constexpr (ATTN == 2) {
         // ---- BertCrossAttention: the tile's 192 columns are the queries of heads 3 tn .. 3 tn + 2 for the band's four dialogs; K and
         // V come from the hoisted cache [B * 64][ldkv] (K at column head * 64, V a plane offset further).  Six phases of (two
@@ -1670,9 +1741,9 @@ static bool gemm_pp_enabled() { return didi_opt(DIDI_OPT_GEMM_PP) != 0; }
 // Per-device set-up, done on the first call on each device: the > 64 KiB dynamic-LDS opt-ins of every big-tile kernel
 // (function attributes live per device) and the device's CU count.  Keyed by the CURRENT device, so a process that
 // drives several GPUs gets each one's own values.
-template <int NPASS, bool F16, bool LN, bool AMAX, int ATTN = 0>
+template <int NPASS, bool F16, bool LN, bool AMAX, int ATTN = 0, bool TN = false>
 static bool opt_in_pp() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<NPASS, F16, LN, AMAX, ATTN>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<NPASS, F16, LN, AMAX, ATTN, TN>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, ATTN == 2 ? XA_LDS_BYTES : PP_LDS_BYTES) == hipSuccess;
 }
 struct DeviceInfo { int state; int ncu; };  // state: 0 = not probed, 1 = ready, -1 = failed
@@ -1694,6 +1765,7 @@ static const DeviceInfo* device_info() {
         ok = ok && opt_in_pp<3, true, false, false>() && opt_in_pp<3, true, false, true>() && opt_in_pp<3, true, true, false>();
         ok = ok && opt_in_pp<1, true, false, false, 1>() && opt_in_pp<2, true, false, false, 1>();
         ok = ok && opt_in_pp<1, true, false, false, 2>() && opt_in_pp<2, true, false, false, 2>();
+        ok = ok && opt_in_pp<3, false, false, false, 0, true>() && opt_in_pp<3, true, false, false, 0, true>() && opt_in_pp<2, true, false, false, 0, true>();
         int c = 0;
         ok = ok && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0;
         d.ncu = c;
@@ -2053,6 +2125,50 @@ extern "C" int didi_gemm_small(const didi_gemm_args* a, const float* gamma, cons
     else if (a->N <= 1024) splitk_ln_kernel<1><<<a->M, 256, 0, st>>>(r);
     else if (a->N <= 2048) splitk_ln_kernel<2><<<a->M, 256, 0, st>>>(r);
     else splitk_ln_kernel<3><<<a->M, 256, 0, st>>>(r);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// ------------------------------------------------------------------ weight gradient from un-transposed operands
+// dW [N, K] = dC^T A for dC [M, N], A [M, K] given as split planes in their natural row-major layout (gemm_pp_kernel's TN form):
+// split-K over the M rows (a few dozen 256x192 output tiles, each walking a share of the batch's rows), partial sums to the
+// workspace, one pass that adds them up.  Supported where the 256x192 split-K form is (small_uses_big_tile) in the two- and
+// three-product precisions; 0 bytes / DIDI_ERR_UNSUPPORTED elsewhere (the caller then transposes and uses didi_gemm_small).
+static int wgrad_splits(int M, int N, int K, int precision) {
+    if (precision != DIDI_PREC_BF16X3 && precision != DIDI_PREC_FP16X2 && precision != DIDI_PREC_FP16X3) return 0;
+    if (N % 8 != 0 || K % 8 != 0 || N < 8 || K < 8) return 0;
+    if (!small_uses_big_tile(N, K, M)) return 0;
+    return small_splits(N, K, M, precision);
+}
+extern "C" size_t didi_gemm_wgrad_workspace_bytes(int M, int N, int K, int precision) {
+    const int ks = wgrad_splits(M, N, K, precision);
+    return ks && allow_big_lds() ? (size_t)ks * N * K * sizeof(float) : 0;
+}
+extern "C" int didi_gemm_wgrad(const uint16_t* dC_hi, const uint16_t* dC_lo, int ldd, const uint16_t* A_hi, const uint16_t* A_lo, int lda, int M, int N,
+                               int K, int precision, float* dW, void* workspace, void* stream) {
+    DIDI_CHECK_ARG(dC_hi && A_hi && dW && workspace && M > 0 && N > 0 && K > 0);
+    const int ks = wgrad_splits(M, N, K, precision);
+    if (!ks || !allow_big_lds()) return DIDI_ERR_UNSUPPORTED;
+    DIDI_CHECK_ARG(ldd % 8 == 0 && lda % 8 == 0 && ldd >= N && lda >= K);
+    DIDI_CHECK_ARG(al16(dC_hi) && al16(dC_lo) && al16(A_hi) && al16(A_lo) && al16(dW) && al16(workspace));
+    GemmParams p{};
+    p.M = N; p.N = K; p.K = M;  // the output's rows come from dC's columns, its columns from A's, the contraction runs over the M rows
+    int rc = fill_operands(p, precision, dC_hi, dC_lo, A_hi, A_lo);
+    if (rc != DIDI_OK) return rc;
+    p.lda = ldd; p.ldw = lda; p.act = DIDI_ACT_NONE;
+    p.C_f32 = reinterpret_cast<float*>(workspace); p.ldc = K;
+    p.k_split = cdiv(M / 128, ks) * 128;
+    p.tiles_m = cdiv(N, 256); p.tiles_n = cdiv(K, BBN);
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(p.tiles_m * p.tiles_n, ks);
+    if (p.npass == 3 && p.f16) gemm_pp_kernel<3, true, false, false, 0, true><<<grid, 512, PP_LDS_BYTES, st>>>(p);
+    else if (p.npass == 3) gemm_pp_kernel<3, false, false, false, 0, true><<<grid, 512, PP_LDS_BYTES, st>>>(p);
+    else gemm_pp_kernel<2, true, false, false, 0, true><<<grid, 512, PP_LDS_BYTES, st>>>(p);
+    DIDI_LAUNCH_CHECK();
+    RowsParams r{};
+    r.part = reinterpret_cast<const float*>(workspace); r.ks = ks; r.M = N; r.N = K;
+    r.act = DIDI_ACT_NONE; r.y_f32 = dW; r.f16 = p.f16;
+    splitk_sum_kernel<<<cdiv((long)N * (K / 4), 256), 256, 0, st>>>(r);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

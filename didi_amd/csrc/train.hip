@@ -335,6 +335,7 @@ __global__ void __launch_bounds__(256) transpose_split_kernel_v4(const float* sr
         for (int k = 0; k < 16; ++k) s += red[k][threadIdx.x];
         partial[(size_t)blockIdx.y * C + c0 + threadIdx.x] = s;
     }
+    if (!hi) return;  // didi_split_both without transposed planes
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = c0 + tr + 16 * j, r = r0 + 4 * tq;  // output row c, output columns r .. r + 3
@@ -385,7 +386,7 @@ extern "C" int didi_transpose_split_colsum(const float* src, int R, int C, int l
 // needs of dC (dgrad reads dC, wgrad dC^T, the bias gradient its column sums).  C % 4 == 0.
 extern "C" int didi_split_both(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
                                int plane_format, float* colsum, void* workspace, void* stream) {
-    DIDI_CHECK_ARG(src && t_hi && p_hi && R > 0 && C > 0 && ldo >= R && ldo == (R + 7) / 8 * 8 && (!colsum || workspace));
+    DIDI_CHECK_ARG(src && p_hi && R > 0 && C > 0 && ldo >= R && ldo == (R + 7) / 8 * 8 && (!colsum || workspace) && (t_hi || !t_lo));
     DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
     if (!transpose_v4_ok(src, C, ldo, t_hi, t_lo) || reinterpret_cast<uintptr_t>(p_hi) % 8 != 0 || reinterpret_cast<uintptr_t>(p_lo) % 8 != 0)
         return DIDI_ERR_UNSUPPORTED;

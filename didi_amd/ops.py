@@ -332,44 +332,71 @@ def transpose_split_colsum(x, dtype=torch.bfloat16):
     return hi, lo, out
 
 
-def split_both(x, dtype=torch.bfloat16, colsum=True):
-    """fp32 [R, C] -> (planes of x [R, C], planes of x^T [C, R8], column sums or None) in one pass (C % 4 == 0)."""
+def split_both(x, dtype=torch.bfloat16, colsum=True, transposed=True):
+    """fp32 [R, C] -> (planes of x [R, C], planes of x^T [C, R8] (None, None without ``transposed``), column sums or None) in one
+    pass (C % 4 == 0)."""
     x = _f32c(x)
     R, Cc = x.shape
     ldo = (R + 7) // 8 * 8
     p_hi = torch.empty((R, Cc), dtype=dtype, device=x.device)
     p_lo = torch.empty_like(p_hi)
-    t_hi = torch.empty((Cc, ldo), dtype=dtype, device=x.device)
-    t_lo = torch.empty_like(t_hi)
+    t_hi = torch.empty((Cc, ldo), dtype=dtype, device=x.device) if transposed else None
+    t_lo = torch.empty_like(t_hi) if transposed else None
     out = torch.empty(Cc, dtype=torch.float32, device=x.device) if colsum else None
     ws = torch.empty(lib.didi_transpose_split_colsum_bytes(R, Cc), dtype=torch.uint8, device=x.device) if colsum else None
-    _lib.check(lib.didi_split_both(x.data_ptr(), R, Cc, ldo, t_hi.data_ptr(), t_lo.data_ptr(), p_hi.data_ptr(), p_lo.data_ptr(), _fmt(dtype),
+    _lib.check(lib.didi_split_both(x.data_ptr(), R, Cc, ldo, _lib.ptr(t_hi), _lib.ptr(t_lo), p_hi.data_ptr(), p_lo.data_ptr(), _fmt(dtype),
                                    _lib.ptr(out), _lib.ptr(ws), _lib.current_stream()), "split_both")
     return (p_hi, p_lo), (t_hi, t_lo), out
 
 
-def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, residual=None, fault=None):
+def wgrad_supported(M, N, K, precision):
+    """Does didi_gemm_wgrad (dW = dC^T A from un-transposed planes) take dC [M, N], A [M, K] in this precision?"""
+    return lib.didi_gemm_wgrad_workspace_bytes(M, N, K, _prec(precision)) > 0
+
+
+def gemm_wgrad(dc_hi, dc_lo, a_hi, a_lo, precision="bf16x3"):
+    """dW [N, K] fp32 = dC^T A from the row-major planes of dC [M, N] and A [M, K] (``wgrad_supported`` shapes only)."""
+    M, N = dc_hi.shape
+    K = a_hi.shape[1]
+    assert a_hi.shape[0] == M and dc_hi.stride(1) == 1 and a_hi.stride(1) == 1
+    nbytes = lib.didi_gemm_wgrad_workspace_bytes(M, N, K, _prec(precision))
+    if not nbytes:
+        raise ValueError(f"didi_gemm_wgrad does not take M={M} N={N} K={K} in {precision}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dc_hi.device)
+    dW = torch.empty((N, K), dtype=torch.float32, device=dc_hi.device)
+    _lib.check(lib.didi_gemm_wgrad(dc_hi.data_ptr(), _lib.ptr(dc_lo), dc_hi.stride(0), a_hi.data_ptr(), _lib.ptr(a_lo), a_hi.stride(0), M, N, K,
+                                   _prec(precision), dW.data_ptr(), ws.data_ptr(), _lib.current_stream()), "gemm_wgrad")
+    return dW
+
+
+def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, residual=None, fault=None, A_planes=None):
     """Backward of C = A W^T + b (nn.Linear): dC [M,N], A [M,K], W [N,K] fp32 -> (dA [M,K] (+ residual), dW [N,K], db [N] or None).
-    dgrad and wgrad are didi_gemm launches on transposed operand planes; db comes out of the pass that transposes dC.
+    dgrad is a didi_gemm launch on the transposed weight planes; wgrad is didi_gemm_wgrad on the planes of dC and of A as they are
+    (``A_planes``: the (hi, lo) the forward multiplied with -- passed, nothing of A is re-read in fp32; A may then be None) where that
+    form applies, else a didi_gemm launch on transposed operand planes; db comes out of the pass that splits dC.
     ``residual`` fp32 [M,K]: added to dA in the dgrad GEMM's epilogue (the gradient of a skip connection joining there)."""
     pd = plane_dtype(precision)
-    dC, A, W = _f32c(dC), _f32c(A), _f32c(W)
+    dC, W = _f32c(dC), _f32c(W)
     M, N = dC.shape
-    K = A.shape[1]
-    one_pass = N % 8 == 0 and need_dA  # dC's planes, its transposed planes and its column sums from one read of dC
+    K = W.shape[1]
+    tn = wgrad_supported(M, N, K, precision) and (A_planes is not None or A is not None)
+    one_pass = N % 8 == 0 and (need_dA or tn)  # dC's planes, its transposed planes and its column sums from one read of dC
     dct = None
-    if one_pass:
+    if tn:
+        (dc_hi, dc_lo), _, db1 = split_both(dC, dtype=pd, colsum=bias, transposed=False)
+        a_hi, a_lo = A_planes if A_planes is not None else split(_f32c(A), dtype=pd)
+    elif one_pass:
         (dc_hi, dc_lo), dct, db1 = split_both(dC, dtype=pd, colsum=bias)
     else:
         dc_hi, dc_lo = split(dC, dtype=pd)
-    wt_hi, wt_lo = transpose_split(W, dtype=pd)          # [K, N8]
-    if wt_hi.shape[1] != N:  # K of this GEMM is N: the A operand must carry the same zero padding
-        pad = wt_hi.shape[1]
-        z = torch.zeros((M, pad), dtype=torch.float32, device=dC.device)
-        z[:, :N] = dC
-        dc_hi, dc_lo = split(z, dtype=pd)
     dA = None
     if need_dA:
+        wt_hi, wt_lo = transpose_split(W, dtype=pd)          # [K, N8]
+        if wt_hi.shape[1] != N:  # K of this GEMM is N: the A operand must carry the same zero padding
+            pad = wt_hi.shape[1]
+            z = torch.zeros((M, pad), dtype=torch.float32, device=dC.device)
+            z[:, :N] = dC
+            dc_hi, dc_lo = split(z, dtype=pd)
         Kd = dc_hi.shape[1]  # the dgrad's contraction length (N, padded to 8)
         K0 = Kd // 64 * 64
         if Kd % 32 != 0 and K0 >= 1024:
@@ -382,6 +409,9 @@ def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, resid
                       residual=head, fault=fault)[2]
         else:
             dA = gemm(dc_hi, dc_lo, wt_hi, wt_lo, precision=precision, out_f32=True, out_planes=False, residual=residual, fault=fault)[2]
+    if tn:
+        return dA, gemm_wgrad(dc_hi, dc_lo, a_hi, a_lo, precision=precision), (db1 if bias else None)
+    A = _f32c(A)
     if dct is not None:
         (dct_hi, dct_lo), db = dct, (db1 if bias else None)
     elif bias:

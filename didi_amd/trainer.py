@@ -214,8 +214,8 @@ class DiDiTrainer:
     def _linear(self, w, a_hi, a_lo, **kw):
         return ops.gemm(a_hi, a_lo, w.hi, w.lo, bias=w.b, precision=self.precision, out_f32=True, fault=self.fault, **kw)
 
-    def _linear_bwd(self, dC, A, w, residual=None, need_dA=True):
-        return ops.linear_backward(dC, A, w.w, precision=self.precision, residual=residual, need_dA=need_dA, fault=self.fault)
+    def _linear_bwd(self, dC, A, w, residual=None, need_dA=True, A_planes=None):
+        return ops.linear_backward(dC, A, w.w, precision=self.precision, residual=residual, need_dA=need_dA, fault=self.fault, A_planes=A_planes)
 
     def check_fault(self, what="training step"):
         """fp16 planes only: wait for the stream and raise if a GEMM of the step wrote a value beyond fp16's range into a plane
@@ -300,14 +300,14 @@ class DiDiTrainer:
         saved = []
         x3 = self.precision in ("bf16x3", "fp16x3")
         for li, (L, ln) in enumerate(zip(self._lin, self._layer_names)):
-            s = dict(h0=h)
+            s = dict(h0=h, h0p=(h_hi, h_lo))  # *p: the planes the forward multiplied with -- the weight gradient's operand as it is
             _, _, qkv = self._linear(L["qkv"], h_hi, h_lo, out_planes=False)
             q3 = qkv.view(B, S, 3 * H)
             s["off_sa"] = site()
             att = ops.attention_train(q3[:, :, :H], q3[:, :, H:2 * H], q3[:, :, 2 * H:], A, causal=True, drop_p=pa, seed=dseed,
                                       offset=s["off_sa"]).view(M, H)
             a_hi, a_lo = ops.split(att, dtype=pd)
-            s["qkv"], s["att"] = qkv, att
+            s["qkv"], s["att"], s["attp"] = qkv, att, (a_hi, a_lo)
             s["off_o"] = site()
             if ph > 0:  # BertSelfOutput: LayerNorm(dropout(dense(x)) + input)
                 _, _, y = self._linear(L["o"], a_hi, a_lo, out_planes=False)
@@ -315,7 +315,7 @@ class DiDiTrainer:
             else:
                 _, _, s1 = self._linear(L["o"], a_hi, a_lo, residual=h, out_planes=False)
             h_hi, h_lo, h1 = ops.layernorm(s1, P[ln["ln1"] + ".weight"], P[ln["ln1"] + ".bias"], eps, f32=True, dtype=pd)
-            s["s1"], s["h1"] = s1, h1
+            s["s1"], s["h1"], s["h1p"] = s1, h1, (h_hi, h_lo)
             _, _, cq = self._linear(L["cq"], h_hi, h_lo, out_planes=False)
             _, _, ckv = self._linear(L["ckv"], x_hi, x_lo, out_planes=False)
             kv3 = ckv.view(B, Cn, 2 * H)
@@ -323,7 +323,7 @@ class DiDiTrainer:
             catt = ops.attention_train(cq.view(B, S, H), kv3[:, :, :H], kv3[:, :, H:], A, causal=False, key_mask=mask32, drop_p=pa,
                                        seed=dseed, offset=s["off_ca"]).view(M, H)
             ca_hi, ca_lo = ops.split(catt, dtype=pd)
-            s["cq"], s["ckv"], s["catt"] = cq, ckv, catt
+            s["cq"], s["ckv"], s["catt"], s["cattp"] = cq, ckv, catt, (ca_hi, ca_lo)
             s["off_co"] = site()
             if ph > 0:
                 _, _, y = self._linear(L["co"], ca_hi, ca_lo, out_planes=False)
@@ -331,10 +331,10 @@ class DiDiTrainer:
             else:
                 _, _, s2 = self._linear(L["co"], ca_hi, ca_lo, residual=h1, out_planes=False)
             h_hi, h_lo, h2 = ops.layernorm(s2, P[ln["ln2"] + ".weight"], P[ln["ln2"] + ".bias"], eps, f32=True, dtype=pd)
-            s["s2"], s["h2"] = s2, h2
+            s["s2"], s["h2"], s["h2p"] = s2, h2, (h_hi, h_lo)
             _, _, u = self._linear(L["up"], h_hi, h_lo, out_planes=False)
             f_hi, f_lo, f_ = self._gelu_planes(u)
-            s["u"], s["f"] = u, f_
+            s["u"], s["f"], s["fp"] = u, f_, (f_hi, f_lo)
             s["off_down"] = site()
             if ph > 0:
                 _, _, y = self._linear(L["down"], f_hi, f_lo, out_planes=False)
@@ -401,36 +401,36 @@ class DiDiTrainer:
 
             ds3, dg, db = ops.layernorm_backward(dh, s["s3"], P[ln["ln3"] + ".weight"], eps)
             put(ln["ln3"], dg, db)
-            df, dW, dbias = self._linear_bwd(drop(ds3, None, s["off_down"]) if ph > 0 else ds3, s["f"], L["down"])
+            df, dW, dbias = self._linear_bwd(drop(ds3, None, s["off_down"]) if ph > 0 else ds3, s["f"], L["down"], A_planes=s["fp"])
             put(ln["down"], dW, dbias)
             du = ops.act_backward("gelu", df, s["u"])
-            dh2, dW, dbias = self._linear_bwd(du, s["h2"], L["up"], residual=ds3)  # + the skip connection around the FFN
+            dh2, dW, dbias = self._linear_bwd(du, s["h2"], L["up"], residual=ds3, A_planes=s["h2p"])  # + the skip connection around the FFN
             put(ln["up"], dW, dbias)
             ds2, dg, db = ops.layernorm_backward(dh2, s["s2"], P[ln["ln2"] + ".weight"], eps)
             put(ln["ln2"], dg, db)
-            dcatt, dW, dbias = self._linear_bwd(drop(ds2, None, s["off_co"]) if ph > 0 else ds2, s["catt"], L["co"])
+            dcatt, dW, dbias = self._linear_bwd(drop(ds2, None, s["off_co"]) if ph > 0 else ds2, s["catt"], L["co"], A_planes=s["cattp"])
             put(ln["co"], dW, dbias)
             ckv = s["ckv"].view(B, Cn, 2 * H)
             dckv = torch.empty_like(ckv)
             dcq = torch.empty((B, S, H), dtype=torch.float32, device=dev)
             ops.attention_backward(s["cq"].view(B, S, H), ckv[:, :, :H], ckv[:, :, H:], dcatt.view(B, S, H), A, causal=False, key_mask=mask32,
                                    out=(dcq, dckv[:, :, :H], dckv[:, :, H:]), drop_p=pa, seed=dseed, offset=s["off_ca"])
-            dh1, dW, dbias = self._linear_bwd(dcq.view(M, H), s["h1"], L["cq"], residual=ds2)
+            dh1, dW, dbias = self._linear_bwd(dcq.view(M, H), s["h1"], L["cq"], residual=ds2, A_planes=s["h1p"])
             put(ln["cq"], dW, dbias)
-            dctx_l, dW, dbias = self._linear_bwd(dckv.view(B * Cn, 2 * H), ctx.view(B * Cn, H), L["ckv"], residual=dctx, need_dA=need_dctx)
+            dctx_l, dW, dbias = self._linear_bwd(dckv.view(B * Cn, 2 * H), ctx.view(B * Cn, H), L["ckv"], residual=dctx, need_dA=need_dctx, A_planes=(x_hi, x_lo))
             put(ln["ck"], dW[:H].contiguous(), dbias[:H].contiguous())
             put(ln["cv"], dW[H:].contiguous(), dbias[H:].contiguous())
             if need_dctx:
                 dctx = dctx_l  # accumulated over the layers in the dgrad epilogue
             ds1, dg, db = ops.layernorm_backward(dh1, s["s1"], P[ln["ln1"] + ".weight"], eps)
             put(ln["ln1"], dg, db)
-            datt, dW, dbias = self._linear_bwd(drop(ds1, None, s["off_o"]) if ph > 0 else ds1, s["att"], L["o"])
+            datt, dW, dbias = self._linear_bwd(drop(ds1, None, s["off_o"]) if ph > 0 else ds1, s["att"], L["o"], A_planes=s["attp"])
             put(ln["o"], dW, dbias)
             qkv = s["qkv"].view(B, S, 3 * H)
             dqkv = torch.empty_like(qkv)
             ops.attention_backward(qkv[:, :, :H], qkv[:, :, H:2 * H], qkv[:, :, 2 * H:], datt.view(B, S, H), A, causal=True,
                                    out=(dqkv[:, :, :H], dqkv[:, :, H:2 * H], dqkv[:, :, 2 * H:]), drop_p=pa, seed=dseed, offset=s["off_sa"])
-            dh0, dW, dbias = self._linear_bwd(dqkv.view(M, 3 * H), s["h0"], L["qkv"], residual=ds1)
+            dh0, dW, dbias = self._linear_bwd(dqkv.view(M, 3 * H), s["h0"], L["qkv"], residual=ds1, A_planes=s["h0p"])
             for j, key in enumerate(("q", "k", "v")):
                 put(ln[key], dW[j * H:(j + 1) * H].contiguous(), dbias[j * H:(j + 1) * H].contiguous())
             dh = dh0

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DIDI_ABI_VERSION 6
+#define DIDI_ABI_VERSION 7
 
 enum {
     DIDI_OK = 0,
@@ -588,8 +588,20 @@ int didi_transpose_split_colsum(const float* src, int R, int C, int ldo, uint16_
  * the transposed planes t_* [C, ldo] (the weight-gradient operand), the un-transposed planes p_* [R, C] (the input-gradient
  * operand) and, when colsum != NULL, the column sums (the bias gradient; workspace as above).  C % 4 == 0, else
  * DIDI_ERR_UNSUPPORTED (callers then make the separate passes). */
+/* t_hi == NULL (ABI 7): no transposed planes -- what is left of the pass when the weight gradient goes through didi_gemm_wgrad. */
 int didi_split_both(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
                     int plane_format, float* colsum, void* workspace, void* stream);
+/* The weight gradient of nn.Linear, dW [N, K] = dC^T A (what `loss.backward()` of src/diffusion/model.py:200-243 computes for every
+ * Linear of the decoder; torch: mm(dC.t(), A)), from the split planes of dC [M, ldd] and A [M, lda] AS THEY LIE IN MEMORY: the
+ * contraction runs over the ROWS of both, the kernel stages [32 rows][256 | 192 columns] tiles and takes its MFMA fragments out of
+ * LDS with transposing reads, so neither dC^T nor A^T is ever written (the two transposing passes per Linear that the
+ * didi_gemm_small route needs).  fp32 result, dense [N, K]; split-K over the rows through `workspace`
+ * (didi_gemm_wgrad_workspace_bytes(M, N, K, precision) bytes, 16-byte aligned; 0 = this shape / precision is not supported and
+ * didi_gemm_wgrad returns DIDI_ERR_UNSUPPORTED: BF16X3, FP16X2 (dC rounded to its hi plane, A exact), FP16X3; M % 128 == 0,
+ * M >= 8192; N >= 512, K >= 192, both % 8 == 0; at most 127 output tiles of 256 x 192).  ldd, lda % 8 == 0, planes 16-byte aligned. */
+size_t didi_gemm_wgrad_workspace_bytes(int M, int N, int K, int precision);
+int didi_gemm_wgrad(const uint16_t* dC_hi, const uint16_t* dC_lo, int ldd, const uint16_t* A_hi, const uint16_t* A_lo, int lda, int M, int N,
+                    int K, int precision, float* dW, void* workspace, void* stream);
 
 /* y = act(x) (fp32, nullable) + its split planes (nullable): the training forward keeps the pre-activation, so GELU is its own
  * pass there.  dx = dy * act'(.) for the two activations on the trained path: DIDI_ACT_GELU takes the PRE-activation (BertIntermediate,

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert getattr(raw, name) is not None
-    assert _lib.lib.didi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib.didi_version() == _lib.ABI_VERSION == 7
     assert b"workspace" in _lib.lib.didi_error_string(-4)
     assert b"fault" in _lib.lib.didi_error_string(_lib.ERR_FAULT)
     assert b"co-resident" in _lib.lib.didi_fault_string(_lib.FAULT_LN_EXCHANGE)

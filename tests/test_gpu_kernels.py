@@ -293,6 +293,36 @@ def test_gemm_split_k_on_the_big_tile(ops, M, N, K, precision):
     assert rel_l2(c, plain) <= 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(16384, 768, 768), (8192, 2304, 768), (16384, 768, 3072), (16512, 1536, 768), (8192, 712, 3000)])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x2", "fp16x3"])
+def test_gemm_wgrad_from_untransposed_planes(ops, M, N, K, precision):
+    """didi_gemm_wgrad: dW [N, K] = dC^T A read from the row-major planes of dC [M, N] and A [M, K] (transposing LDS reads; no
+    transposed copy).  Against fp64 on the same rounded operands -- the decoder's five weight shapes at the training batch, a last
+    split shorter than the others (16512 rows), ragged last tiles on both sides (712 x 3000) -- and against the route it replaces
+    (transposed planes through didi_gemm_small) to summation-order rounding."""
+    dc, a = rnd(M, N, seed=53, scale=0.02), rnd(M, K, seed=54)
+    pd = PD[precision]
+    assert ops.wgrad_supported(M, N, K, precision)
+    d_hi, d_lo = ops.split(dc.cuda(), dtype=pd)
+    a_hi, a_lo = ops.split(a.cuda(), dtype=pd)
+    dW = ops.gemm_wgrad(d_hi, d_lo, a_hi, a_lo, precision=precision)
+    dr = d_hi.double().cpu() if precision == "fp16x2" else ops.join(d_hi, d_lo).double().cpu()  # fp16x2: the first operand enters as its hi plane
+    want = dr.t() @ ops.join(a_hi, a_lo).double().cpu()
+    assert dW.shape == (N, K) and rel_l2(dW, want) <= 5e-6, rel_l2(dW, want)
+    dt_hi, dt_lo = ops.transpose_split(dc.cuda(), dtype=pd)
+    at_hi, at_lo = ops.transpose_split(a.cuda(), dtype=pd)
+    _, _, old = ops.gemm(dt_hi, dt_lo, at_hi, at_lo, precision=precision, out_f32=True, out_planes=False)
+    assert rel_l2(dW, old) <= 2e-6, rel_l2(dW, old)
+
+
+def test_gemm_wgrad_limits(ops):
+    assert not ops.wgrad_supported(4096, 768, 768, "bf16x3")     # too few rows for the split-K form
+    assert not ops.wgrad_supported(16384, 768, 768, "fp16")      # one-product precisions keep the transposing route
+    assert not ops.wgrad_supported(16384, 8008, 768, "bf16x3")   # 128 output tiles fill the chip without a split
+    assert not ops.wgrad_supported(16384, 768, 100, "bf16x3")
+    assert not ops.wgrad_supported(16400, 768, 768, "bf16x3")    # rows not a multiple of 128
+
+
 def test_gemm_small_batch_form_limits(ops):
     from didi_amd._lib import lib
 

@@ -191,6 +191,9 @@ SYMBOLS = [
     ("didi_gemm_wgrad_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("didi_gemm_wgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
+    ("didi_gemm_dgrad_supported", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("didi_gemm_dgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     ("didi_split_both", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     ("didi_act_backward", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

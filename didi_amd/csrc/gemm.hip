@@ -714,10 +714,14 @@ __device__ __forceinline__ bf16x8 lds_tr8(const char* p0, const char* p1) {
 // out of it through ds_read_b64_tr_b16, which hands lane lr column lr of a 4 x 16 block addressed row-wise by the 16 lanes.
 // Lane (lr, lg)'s eight contraction indices are then {4 lg .. 4 lg + 3, 16 + 4 lg ..} in BOTH fragments instead of 8 lg .. 8 lg + 7:
 // a permutation of the sum, nothing else.  Raw fp32 sums out (split-K partials), accumulator tile ni = 16 consecutive columns.
-template <int NPASS, bool F16, bool LN, bool AMAX = false, int ATTN = 0, bool TN = false>
+// TN = 3 is that form.  TN = 2 is the input-gradient form (didi_gemm_dgrad): dA[m][k] = sum_n dC[m][n] W[n][k] takes ONLY the weight
+// side from a row-indexed source (W_* = the forward's own weight planes [K][ldw]); the activation side stays as it is, so the
+// transposing reads take rows 8 lg .. 8 lg + 3 and 8 lg + 4 .. of the K-tile and the fragments pair index for index.  fp32 out
+// (+ the fp32 residual), no bias.
+template <int NPASS, bool F16, bool LN, bool AMAX = false, int ATTN = 0, int TN = 0>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     using G = BigGeom<4>;
-    static_assert(!TN || (NPASS != 1 && !LN && !AMAX && ATTN == 0), "the transposed-source form: two- / three-product split-K launches only");
+    static_assert(TN == 0 || ((TN == 2 || TN == 3) && NPASS != 1 && !LN && !AMAX && ATTN == 0), "the transposed-source forms: two- / three-product launches only");
     constexpr int BKK = NPASS == 1 ? 64 : 32;
     constexpr int CPR = BKK * 2 / 16, RPI = 64 / CPR;   // 16-byte chunks per LDS row, rows per DMA piece
     constexpr int NYP = NPASS == 2 ? 4 : 8;             // activation pieces per wave of group Y (fp16x2 stages no A_lo tile)
@@ -738,7 +742,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     if constexpr (!LN && !AMAX && ATTN == 0) {
         if (p.k_split) {  // split-K form (didi_gemm_small on weight-gradient shapes): K columns [y k_split, ...), raw partial sums
             const int k0 = blockIdx.y * p.k_split;
-            const size_t ka = TN ? (size_t)k0 * p.lda : k0, kw = TN ? (size_t)k0 * p.ldw : k0;
+            const size_t ka = TN == 3 ? (size_t)k0 * p.lda : k0, kw = TN ? (size_t)k0 * p.ldw : k0;
             p.A_hi += ka; p.A_lo += ka; p.W_hi += kw; p.W_lo += kw;
             p.K = min(p.k_split, p.K - k0);
             p.C_f32 += (size_t)blockIdx.y * p.M * p.ldc;
@@ -770,18 +774,19 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         } else {
             base = grp ? p.A_hi : p.W_hi; row = q * RPI;
         }
-        if constexpr (TN) {
+        if (TN == 3 || (TN == 2 && !grp)) {
             // piece q (1 KiB of LDS, lane l at byte 16 l) of a [32][256] activation-side or [32][192] weight-side K-tile: LDS row kk,
             // 16-byte position c_ in it.  The source chunk that goes there: activation side c_ ^ 2 (kk & 7), weight side the 32-byte
             // pair rotated by kk >> 1 (mod 12) -- the eight rows one ds_read_b64_tr_b16 touches per half wave then fall on eight
-            // different bank groups (row strides 512 B and 384 B)
+            // different bank groups (row strides 512 B and 384 B).  TN = 2 reads rows {0..3, 8..11} (+ 4, + 16) together: rotation
+            // ((kk >> 1) & 1) + 2 ((kk >> 3) & 1)
             int kk, c;
             if (grp) { kk = 2 * (q & 15) + (lane >> 5); c = (lane & 31) ^ ((kk & 7) << 1); }
             else {
                 const int idx = (q < 12 ? q : q - 12) * 64 + lane;
                 kk = idx / 24;
                 const int c_ = idx - kk * 24;
-                int pr = (c_ >> 1) - ((kk >> 1) % 12);
+                int pr = (c_ >> 1) - (TN == 3 ? (kk >> 1) % 12 : ((kk >> 1) & 1) + 2 * ((kk >> 3) & 1));
                 pr += pr < 0 ? 12 : 0;
                 c = 2 * pr + (c_ & 1);
             }
@@ -803,19 +808,29 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
         qoff[j] = (grp ? 0 : W_OFF) + q * 1024;
     }
     const int nt = p.K / BKK;
-    const size_t kstep = TN ? (size_t)BKK * (grp ? p.lda : p.ldw) : BKK;  // elements from one K-tile to the next
+    const size_t kstep = grp ? (TN == 3 ? (size_t)BKK * p.lda : BKK) : (TN ? (size_t)BKK * p.ldw : BKK);  // elements from one K-tile to the next
 #define PP_ISSUE(T, BUF, N)                                                                          \
     do {                                                                                             \
         char* st_ = smem + (BUF) * STAGE;                                                            \
         _Pragma("unroll") for (int j = 0; j < (N); ++j) {                                            \
-            if constexpr (TN) glds16_raw(src[j] + (T) * kstep, st_ + qoff[j]); /* no compiler-made vmcnt(0) before the transposing reads */ \
+            if constexpr (TN != 0) glds16_raw(src[j] + (T) * kstep, st_ + qoff[j]); /* no compiler-made vmcnt(0) before the transposing reads */ \
             else glds16(src[j] + (T) * kstep, st_ + qoff[j]);                                        \
         }                                                                                            \
     } while (0)
     // TN: byte offsets of this lane's transposing reads.  The lane addresses row 4 lg + (lr >> 2) (and 16 below it) of the K-tile,
     // columns 4 (lr & 3) .. + 3 of the fragment's 16
     int ta[4], tw0[6], tw1[6];
-    if constexpr (TN) {
+    if constexpr (TN == 2) {
+        const int kk = 8 * lg + (lr >> 2), sub = 8 * (lr & 1), hc = (lr & 3) >> 1;  // second read: 4 rows below (same rotation)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            int p0 = wn * 6 + i + ((kk >> 1) & 1) + 2 * ((kk >> 3) & 1);
+            p0 -= p0 >= 12 ? 12 : 0;
+            tw0[i] = kk * 384 + p0 * 32 + hc * 16 + sub;
+            tw1[i] = tw0[i] + 4 * 384;
+        }
+    }
+    if constexpr (TN == 3) {
         const int kk = 4 * lg + (lr >> 2), sub = 8 * (lr & 1), hc = (lr & 3) >> 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ta[i] = kk * 512 + (((wm * 8 + i * 2 + hc) ^ ((kk & 7) << 1)) << 4) + sub;
@@ -833,14 +848,20 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
     bf16x8 fw[12], fa[8];
 #define PP_READ(ST)                                                                                        \
     do {                                                                                                   \
-        if constexpr (TN) {                                                                                \
+        if constexpr (TN != 0) {                                                                           \
             _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                \
                 fw[i] = lds_tr8((ST) + W_OFF + tw0[i], (ST) + W_OFF + tw1[i]);                             \
                 fw[6 + i] = lds_tr8((ST) + W_OFF + LO_W + tw0[i], (ST) + W_OFF + LO_W + tw1[i]);           \
             }                                                                                              \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
-                fa[i] = lds_tr8((ST) + ta[i], (ST) + ta[i] + 8192);                                        \
-                if constexpr (NPASS == 3) fa[4 + i] = lds_tr8((ST) + LO_A + ta[i], (ST) + LO_A + ta[i] + 8192); \
+                if constexpr (TN == 3) {                                                                   \
+                    fa[i] = lds_tr8((ST) + ta[i], (ST) + ta[i] + 8192);                                    \
+                    if constexpr (NPASS == 3) fa[4 + i] = lds_tr8((ST) + LO_A + ta[i], (ST) + LO_A + ta[i] + 8192); \
+                } else {                                                                                   \
+                    const int ao = swz64(wm * 64 + i * 16 + lr, lg);                                       \
+                    fa[i] = *reinterpret_cast<const bf16x8*>((ST) + ao);                                   \
+                    if constexpr (NPASS == 3) fa[4 + i] = *reinterpret_cast<const bf16x8*>((ST) + LO_A + ao); \
+                }                                                                                          \
             }                                                                                              \
         } else if constexpr (NPASS != 1) {                                                                 \
             _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                \
@@ -1008,15 +1029,23 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmParams p) {
 #undef PP_READ
 #undef PP_MFMA
     PP_STAMP(2);  // K-loop done (this wave group)
-    if constexpr (TN) {  // raw sums: acc[ni][mi][r] = C[m0 + 64 wm + 16 mi + lr][n0 + 96 wn + 16 ni + 4 lg + r]
+    if constexpr (TN != 0) {  // raw sums (+ fp32 residual): acc[ni][mi][r] = C[m0 + 64 wm + 16 mi + lr][n0 + 96 wn + 16 ni + 4 lg + r]
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int m = m0 + wm * 64 + mi * 16 + lr;
+            float4 rr[6];
+#pragma unroll
+            for (int ni = 0; ni < 6; ++ni) {  // the residual's six loads first, then the stores
+                const int n = n0 + wn * 96 + ni * 16 + 4 * lg;
+                rr[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (TN == 2 && p.R_f32 && m < p.M && n < p.N) rr[ni] = *reinterpret_cast<const float4*>(p.R_f32 + (size_t)m * p.ldr + n);
+            }
 #pragma unroll
             for (int ni = 0; ni < 6; ++ni) {
                 const int n = n0 + wn * 96 + ni * 16 + 4 * lg;
                 if (m < p.M && n < p.N)  // N % 8 == 0: n + 3 < N too
-                    *reinterpret_cast<float4*>(p.C_f32 + (size_t)m * p.ldc + n) = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+                    *reinterpret_cast<float4*>(p.C_f32 + (size_t)m * p.ldc + n) =
+                        make_float4(acc[ni][mi][0] + rr[ni].x, acc[ni][mi][1] + rr[ni].y, acc[ni][mi][2] + rr[ni].z, acc[ni][mi][3] + rr[ni].w);
             }
         }
         return;
@@ -1741,7 +1770,7 @@ static bool gemm_pp_enabled() { return didi_opt(DIDI_OPT_GEMM_PP) != 0; }
 // Per-device set-up, done on the first call on each device: the > 64 KiB dynamic-LDS opt-ins of every big-tile kernel
 // (function attributes live per device) and the device's CU count.  Keyed by the CURRENT device, so a process that
 // drives several GPUs gets each one's own values.
-template <int NPASS, bool F16, bool LN, bool AMAX, int ATTN = 0, bool TN = false>
+template <int NPASS, bool F16, bool LN, bool AMAX, int ATTN = 0, int TN = 0>
 static bool opt_in_pp() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<NPASS, F16, LN, AMAX, ATTN, TN>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, ATTN == 2 ? XA_LDS_BYTES : PP_LDS_BYTES) == hipSuccess;
@@ -1765,7 +1794,8 @@ static const DeviceInfo* device_info() {
         ok = ok && opt_in_pp<3, true, false, false>() && opt_in_pp<3, true, false, true>() && opt_in_pp<3, true, true, false>();
         ok = ok && opt_in_pp<1, true, false, false, 1>() && opt_in_pp<2, true, false, false, 1>();
         ok = ok && opt_in_pp<1, true, false, false, 2>() && opt_in_pp<2, true, false, false, 2>();
-        ok = ok && opt_in_pp<3, false, false, false, 0, true>() && opt_in_pp<3, true, false, false, 0, true>() && opt_in_pp<2, true, false, false, 0, true>();
+        ok = ok && opt_in_pp<3, false, false, false, 0, 3>() && opt_in_pp<3, true, false, false, 0, 3>() && opt_in_pp<2, true, false, false, 0, 3>();
+        ok = ok && opt_in_pp<3, false, false, false, 0, 2>() && opt_in_pp<3, true, false, false, 0, 2>() && opt_in_pp<2, true, false, false, 0, 2>();
         int c = 0;
         ok = ok && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0;
         d.ncu = c;
@@ -2161,14 +2191,44 @@ extern "C" int didi_gemm_wgrad(const uint16_t* dC_hi, const uint16_t* dC_lo, int
     p.tiles_m = cdiv(N, 256); p.tiles_n = cdiv(K, BBN);
     hipStream_t st = as_stream(stream);
     const dim3 grid(p.tiles_m * p.tiles_n, ks);
-    if (p.npass == 3 && p.f16) gemm_pp_kernel<3, true, false, false, 0, true><<<grid, 512, PP_LDS_BYTES, st>>>(p);
-    else if (p.npass == 3) gemm_pp_kernel<3, false, false, false, 0, true><<<grid, 512, PP_LDS_BYTES, st>>>(p);
-    else gemm_pp_kernel<2, true, false, false, 0, true><<<grid, 512, PP_LDS_BYTES, st>>>(p);
+    if (p.npass == 3 && p.f16) gemm_pp_kernel<3, true, false, false, 0, 3><<<grid, 512, PP_LDS_BYTES, st>>>(p);
+    else if (p.npass == 3) gemm_pp_kernel<3, false, false, false, 0, 3><<<grid, 512, PP_LDS_BYTES, st>>>(p);
+    else gemm_pp_kernel<2, true, false, false, 0, 3><<<grid, 512, PP_LDS_BYTES, st>>>(p);
     DIDI_LAUNCH_CHECK();
     RowsParams r{};
     r.part = reinterpret_cast<const float*>(workspace); r.ks = ks; r.M = N; r.N = K;
     r.act = DIDI_ACT_NONE; r.y_f32 = dW; r.f16 = p.f16;
     splitk_sum_kernel<<<cdiv((long)N * (K / 4), 256), 256, 0, st>>>(r);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
+// dA [M, K] = dC [M, N] W [N, K] (+ residual): nn.Linear's input gradient with the weight planes as the forward holds them
+// (gemm_pp_kernel's TN = 2 form: the weight side is read row-indexed, no transposed copy of W).
+extern "C" int didi_gemm_dgrad_supported(int M, int N, int K, int precision) {
+    if (precision != DIDI_PREC_BF16X3 && precision != DIDI_PREC_FP16X2 && precision != DIDI_PREC_FP16X3) return 0;
+    return M >= 2048 && N >= 32 && N % 32 == 0 && K >= BBN && K % 8 == 0 && (long)cdiv(K, BBN) * BBN * 100 <= (long)K * 115 &&
+           didi_opt(DIDI_OPT_GEMM_BIG) != 0 && didi_opt(DIDI_OPT_GEMM_PP) != 0 && allow_big_lds();
+}
+extern "C" int didi_gemm_dgrad(const uint16_t* dC_hi, const uint16_t* dC_lo, int ldd, const uint16_t* W_hi, const uint16_t* W_lo, int ldw, int M, int N,
+                               int K, int precision, const float* R_f32, int ldr, float* dA, int lda, void* stream) {
+    DIDI_CHECK_ARG(dC_hi && W_hi && dA && M > 0 && N > 0 && K > 0);
+    if (!didi_gemm_dgrad_supported(M, N, K, precision)) return DIDI_ERR_UNSUPPORTED;
+    DIDI_CHECK_ARG(ldd % 8 == 0 && ldw % 8 == 0 && lda % 4 == 0 && ldd >= N && ldw >= K && lda >= K && (!R_f32 || (ldr % 4 == 0 && ldr >= K)));
+    DIDI_CHECK_ARG(al16(dC_hi) && al16(dC_lo) && al16(W_hi) && al16(W_lo) && al16(dA) && al16(R_f32));
+    GemmParams p{};
+    p.M = M; p.N = K; p.K = N;  // the output's columns are W's columns, the contraction runs over W's rows
+    int rc = fill_operands(p, precision, dC_hi, dC_lo, W_hi, W_lo);
+    if (rc != DIDI_OK) return rc;
+    p.lda = ldd; p.ldw = ldw; p.act = DIDI_ACT_NONE;
+    p.R_f32 = R_f32; p.ldr = ldr;
+    p.C_f32 = dA; p.ldc = lda;
+    p.tiles_m = cdiv(M, 256); p.tiles_n = cdiv(K, BBN);
+    hipStream_t st = as_stream(stream);
+    const int grid = p.tiles_m * p.tiles_n;
+    if (p.npass == 3 && p.f16) gemm_pp_kernel<3, true, false, false, 0, 2><<<grid, 512, PP_LDS_BYTES, st>>>(p);
+    else if (p.npass == 3) gemm_pp_kernel<3, false, false, false, 0, 2><<<grid, 512, PP_LDS_BYTES, st>>>(p);
+    else gemm_pp_kernel<2, true, false, false, 0, 2><<<grid, 512, PP_LDS_BYTES, st>>>(p);
     DIDI_LAUNCH_CHECK();
     return DIDI_OK;
 }

@@ -369,11 +369,31 @@ def gemm_wgrad(dc_hi, dc_lo, a_hi, a_lo, precision="bf16x3"):
     return dW
 
 
-def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, residual=None, fault=None, A_planes=None):
+def dgrad_supported(M, N, K, precision):
+    """Does didi_gemm_dgrad (dA = dC W from W's own planes) take dC [M, N], W [N, K] in this precision?"""
+    return lib.didi_gemm_dgrad_supported(M, N, K, _prec(precision)) != 0
+
+
+def gemm_dgrad(dc_hi, dc_lo, w_hi, w_lo, precision="bf16x3", residual=None):
+    """dA [M, K] fp32 = dC W (+ residual fp32 [M, K]) from the planes of dC [M, N] and of W [N, K] as the forward holds them."""
+    M, N = dc_hi.shape
+    K = w_hi.shape[1]
+    assert w_hi.shape[0] == N and dc_hi.stride(1) == 1 and w_hi.stride(1) == 1
+    if residual is not None:
+        residual = _f32c(residual)
+        assert residual.shape == (M, K)
+    dA = torch.empty((M, K), dtype=torch.float32, device=dc_hi.device)
+    _lib.check(lib.didi_gemm_dgrad(dc_hi.data_ptr(), _lib.ptr(dc_lo), dc_hi.stride(0), w_hi.data_ptr(), _lib.ptr(w_lo), w_hi.stride(0), M, N, K,
+                                   _prec(precision), _lib.ptr(residual), K, dA.data_ptr(), K, _lib.current_stream()), "gemm_dgrad")
+    return dA
+
+
+def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, residual=None, fault=None, A_planes=None, W_planes=None):
     """Backward of C = A W^T + b (nn.Linear): dC [M,N], A [M,K], W [N,K] fp32 -> (dA [M,K] (+ residual), dW [N,K], db [N] or None).
     dgrad is a didi_gemm launch on the transposed weight planes; wgrad is didi_gemm_wgrad on the planes of dC and of A as they are
     (``A_planes``: the (hi, lo) the forward multiplied with -- passed, nothing of A is re-read in fp32; A may then be None) where that
-    form applies, else a didi_gemm launch on transposed operand planes; db comes out of the pass that splits dC.
+    form applies, else a didi_gemm launch on transposed operand planes; with ``W_planes`` (the forward's weight planes) dgrad is
+    didi_gemm_dgrad on them where that form applies (no transposed copy of W); db comes out of the pass that splits dC.
     ``residual`` fp32 [M,K]: added to dA in the dgrad GEMM's epilogue (the gradient of a skip connection joining there)."""
     pd = plane_dtype(precision)
     dC, W = _f32c(dC), _f32c(W)
@@ -390,7 +410,9 @@ def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, resid
     else:
         dc_hi, dc_lo = split(dC, dtype=pd)
     dA = None
-    if need_dA:
+    if need_dA and W_planes is not None and dgrad_supported(M, N, K, precision):
+        dA = gemm_dgrad(dc_hi, dc_lo, W_planes[0], W_planes[1], precision=precision, residual=residual)
+    elif need_dA:
         wt_hi, wt_lo = transpose_split(W, dtype=pd)          # [K, N8]
         if wt_hi.shape[1] != N:  # K of this GEMM is N: the A operand must carry the same zero padding
             pad = wt_hi.shape[1]

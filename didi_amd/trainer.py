@@ -215,7 +215,8 @@ class DiDiTrainer:
         return ops.gemm(a_hi, a_lo, w.hi, w.lo, bias=w.b, precision=self.precision, out_f32=True, fault=self.fault, **kw)
 
     def _linear_bwd(self, dC, A, w, residual=None, need_dA=True, A_planes=None):
-        return ops.linear_backward(dC, A, w.w, precision=self.precision, residual=residual, need_dA=need_dA, fault=self.fault, A_planes=A_planes)
+        return ops.linear_backward(dC, A, w.w, precision=self.precision, residual=residual, need_dA=need_dA, fault=self.fault, A_planes=A_planes,
+                                   W_planes=(w.hi, w.lo))
 
     def check_fault(self, what="training step"):
         """fp16 planes only: wait for the stream and raise if a GEMM of the step wrote a value beyond fp16's range into a plane
@@ -333,7 +334,7 @@ class DiDiTrainer:
             h_hi, h_lo, h2 = ops.layernorm(s2, P[ln["ln2"] + ".weight"], P[ln["ln2"] + ".bias"], eps, f32=True, dtype=pd)
             s["s2"], s["h2"], s["h2p"] = s2, h2, (h_hi, h_lo)
             _, _, u = self._linear(L["up"], h_hi, h_lo, out_planes=False)
-            f_hi, f_lo, f_ = self._gelu_planes(u)
+            f_hi, f_lo, f_ = self._gelu_planes(u, H)
             s["u"], s["f"], s["fp"] = u, f_, (f_hi, f_lo)
             s["off_down"] = site()
             if ph > 0:
@@ -479,10 +480,11 @@ class DiDiTrainer:
             out.update(emb=emb, x_0=x_0, x_t=x_t, x_0_hat=x_0_hat, d_x_0_hat=d_x0_hat.view(B, S, H) / ls)
         return out
 
-    def _gelu_planes(self, u):
-        """gelu(u) as planes + fp32: the exact erf form of the GEMM epilogue, here as its own pass because the backward keeps
-        the PRE-activation."""
-        return ops.act_forward("gelu", u, dtype=self._pd)
+    def _gelu_planes(self, u, H):
+        """gelu(u) as planes (+ fp32 only where the weight gradient of the next Linear still wants its input in fp32): the exact erf
+        form of the GEMM epilogue, here as its own pass because the backward keeps the PRE-activation."""
+        M, F = u.shape
+        return ops.act_forward("gelu", u, dtype=self._pd, f32=not ops.wgrad_supported(M, H, F, self.precision))
 
     # ------------------------------------------------------------------ optimiser (model.py:136-158, train.yaml:33-45)
     def lr_at(self, step):

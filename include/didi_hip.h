@@ -600,6 +600,15 @@ int didi_split_both(const float* src, int R, int C, int ldo, uint16_t* t_hi, uin
  * didi_gemm_wgrad returns DIDI_ERR_UNSUPPORTED: BF16X3, FP16X2 (dC rounded to its hi plane, A exact), FP16X3; M % 128 == 0,
  * M >= 8192; N >= 512, K >= 192, both % 8 == 0; at most 127 output tiles of 256 x 192).  ldd, lda % 8 == 0, planes 16-byte aligned. */
 size_t didi_gemm_wgrad_workspace_bytes(int M, int N, int K, int precision);
+/* The input gradient of nn.Linear, dA [M, lda] = dC [M, N] W [N, K] (+ R_f32 [M, ldr], nullable: the gradient arriving over a skip
+ * connection; torch: mm(dC, W)), with W's planes as the FORWARD holds them ([N, ldw] row-major: the contraction runs over W's rows,
+ * which the kernel reads through transposing LDS reads -- no transposed copy of the weights per step).  fp32 out, no bias.
+ * Supported (didi_gemm_dgrad_supported != 0, else DIDI_ERR_UNSUPPORTED and the caller transposes W and uses didi_gemm): BF16X3,
+ * FP16X2 (dC rounded to its hi plane, W exact), FP16X3; M >= 2048; N % 32 == 0; K >= 192, K % 8 == 0 with at most 15 % of the last
+ * 192-column tile empty.  ldd, ldw % 8 == 0, lda, ldr % 4 == 0, everything 16-byte aligned. */
+int didi_gemm_dgrad_supported(int M, int N, int K, int precision);
+int didi_gemm_dgrad(const uint16_t* dC_hi, const uint16_t* dC_lo, int ldd, const uint16_t* W_hi, const uint16_t* W_lo, int ldw, int M, int N,
+                    int K, int precision, const float* R_f32, int ldr, float* dA, int lda, void* stream);
 int didi_gemm_wgrad(const uint16_t* dC_hi, const uint16_t* dC_lo, int ldd, const uint16_t* A_hi, const uint16_t* A_lo, int lda, int M, int N,
                     int K, int precision, float* dW, void* workspace, void* stream);
 

@@ -315,12 +315,37 @@ def test_gemm_wgrad_from_untransposed_planes(ops, M, N, K, precision):
     assert rel_l2(dW, old) <= 2e-6, rel_l2(dW, old)
 
 
+@pytest.mark.parametrize("M,N,K", [(16384, 768, 768), (8192, 2304, 768), (4096, 3072, 768), (8192, 768, 3072), (2100, 1536, 3000)])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x2", "fp16x3"])
+def test_gemm_dgrad_from_the_forward_weight_planes(ops, M, N, K, precision):
+    """didi_gemm_dgrad: dA [M, K] = dC W + residual with W [N, K] read as the forward holds it (transposing LDS reads on the weight
+    side only).  Against fp64 on the same rounded operands -- the decoder's four shapes, ragged last tiles on both sides (2100 x
+    3000) -- and against the route it replaces (didi_gemm on a transposed copy of W) to summation-order rounding."""
+    dc, w, r = rnd(M, N, seed=57, scale=0.02), rnd(N, K, seed=58, scale=0.05), rnd(M, K, seed=59)
+    pd = PD[precision]
+    assert ops.dgrad_supported(M, N, K, precision)
+    d_hi, d_lo = ops.split(dc.cuda(), dtype=pd)
+    w_hi, w_lo = ops.split(w.cuda(), dtype=pd)
+    dA = ops.gemm_dgrad(d_hi, d_lo, w_hi, w_lo, precision=precision, residual=r.cuda())
+    dr = d_hi.double().cpu() if precision == "fp16x2" else ops.join(d_hi, d_lo).double().cpu()
+    want = dr @ ops.join(w_hi, w_lo).double().cpu() + r.double()
+    assert dA.shape == (M, K) and rel_l2(dA, want) <= 5e-6, rel_l2(dA, want)
+    wt_hi, wt_lo = ops.transpose_split(w.cuda(), dtype=pd)
+    _, _, old = ops.gemm(d_hi, d_lo, wt_hi, wt_lo, precision=precision, out_f32=True, out_planes=False, residual=r.cuda())
+    assert rel_l2(dA, old) <= 2e-6, rel_l2(dA, old)
+    plain = ops.gemm_dgrad(d_hi, d_lo, w_hi, w_lo, precision=precision)
+    assert rel_l2(plain, want - r.double()) <= 5e-6
+
+
 def test_gemm_wgrad_limits(ops):
     assert not ops.wgrad_supported(4096, 768, 768, "bf16x3")     # too few rows for the split-K form
     assert not ops.wgrad_supported(16384, 768, 768, "fp16")      # one-product precisions keep the transposing route
     assert not ops.wgrad_supported(16384, 8008, 768, "bf16x3")   # 128 output tiles fill the chip without a split
     assert not ops.wgrad_supported(16384, 768, 100, "bf16x3")
     assert not ops.wgrad_supported(16400, 768, 768, "bf16x3")    # rows not a multiple of 128
+    assert not ops.dgrad_supported(1024, 768, 768, "bf16x3")     # too few rows for the 256-row tile to pay
+    assert not ops.dgrad_supported(16384, 8008, 768, "bf16x3")   # contraction not a multiple of the K-step (the classifier)
+    assert not ops.dgrad_supported(16384, 768, 768, "bf16")
 
 
 def test_gemm_small_batch_form_limits(ops):

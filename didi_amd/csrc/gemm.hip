@@ -1978,8 +1978,11 @@ static int small_splits(int M, int N, int K, int precision) {
     const int unit = 128;  // K columns per split are a multiple of this (two one-product K-tiles, four bf16x3 ones)
     if (K % unit != 0 || K < 2 * unit) return 0;
     if (precision != DIDI_PREC_BF16 && precision != DIDI_PREC_FP16 && precision != DIDI_PREC_BF16X3 && precision != DIDI_PREC_FP16X2 && precision != DIDI_PREC_FP16X3) return 0;
-    const int wgs = small_uses_big_tile(M, N, K) ? cdiv(M, 256) * cdiv(N, BBN) : cdiv(M, BM) * cdiv(N, BN);
-    int ks = std::min(cdiv(256, wgs), K / unit);
+    // the 128x128 kernel runs two or more workgroups per CU (any count near 256 tiles x splits is one round); the 256x192 kernel
+    // runs ONE, so its tiles x splits must not exceed the CUs: 264 workgroups are two rounds, the second one 3 % full
+    const bool big = small_uses_big_tile(M, N, K);
+    const int wgs = big ? cdiv(M, 256) * cdiv(N, BBN) : cdiv(M, BM) * cdiv(N, BN);
+    int ks = std::min(big ? std::max(256 / wgs, 1) : cdiv(256, wgs), K / unit);
     if (ks < 2) return 0;
     const int kc = cdiv(K / unit, ks) * unit;
     return cdiv(K, kc);
@@ -2164,21 +2167,28 @@ extern "C" int didi_gemm_small(const didi_gemm_args* a, const float* gamma, cons
 // split-K over the M rows (a few dozen 256x192 output tiles, each walking a share of the batch's rows), partial sums to the
 // workspace, one pass that adds them up.  Supported where the 256x192 split-K form is (small_uses_big_tile) in the two- and
 // three-product precisions; 0 bytes / DIDI_ERR_UNSUPPORTED elsewhere (the caller then transposes and uses didi_gemm_small).
-static int wgrad_splits(int M, int N, int K, int precision) {
+// rows per split (a multiple of the 32-row K-tile; 0 = not supported): as many splits as keep tiles x splits within the CUs (one
+// workgroup per CU: everything runs in one round), rows spread evenly over them
+static int wgrad_rows_per_split(int M, int N, int K, int precision) {
     if (precision != DIDI_PREC_BF16X3 && precision != DIDI_PREC_FP16X2 && precision != DIDI_PREC_FP16X3) return 0;
-    if (N % 8 != 0 || K % 8 != 0 || N < 8 || K < 8) return 0;
-    if (!small_uses_big_tile(N, K, M)) return 0;
-    return small_splits(N, K, M, precision);
+    if (N % 8 != 0 || K % 8 != 0 || M % 32 != 0 || M < 8192 || N < 512 || K < BBN) return 0;
+    if ((long)cdiv(K, BBN) * BBN * 100 > (long)K * 115 || didi_opt(DIDI_OPT_GEMM_BIG) == 0 || didi_opt(DIDI_OPT_GEMM_PP) == 0) return 0;
+    const DeviceInfo* d = device_info();
+    const int tiles = cdiv(N, 256) * cdiv(K, BBN);
+    if (!d || tiles >= 128 || tiles > d->ncu / 2) return 0;
+    const int ks = d->ncu / tiles;
+    return cdiv(M / 32, ks) * 32;
 }
 extern "C" size_t didi_gemm_wgrad_workspace_bytes(int M, int N, int K, int precision) {
-    const int ks = wgrad_splits(M, N, K, precision);
-    return ks && allow_big_lds() ? (size_t)ks * N * K * sizeof(float) : 0;
+    const int kc = wgrad_rows_per_split(M, N, K, precision);
+    return kc ? (size_t)cdiv(M, kc) * N * K * sizeof(float) : 0;
 }
 extern "C" int didi_gemm_wgrad(const uint16_t* dC_hi, const uint16_t* dC_lo, int ldd, const uint16_t* A_hi, const uint16_t* A_lo, int lda, int M, int N,
                                int K, int precision, float* dW, void* workspace, void* stream) {
     DIDI_CHECK_ARG(dC_hi && A_hi && dW && workspace && M > 0 && N > 0 && K > 0);
-    const int ks = wgrad_splits(M, N, K, precision);
-    if (!ks || !allow_big_lds()) return DIDI_ERR_UNSUPPORTED;
+    const int kc = wgrad_rows_per_split(M, N, K, precision);
+    if (!kc) return DIDI_ERR_UNSUPPORTED;
+    const int ks = cdiv(M, kc);
     DIDI_CHECK_ARG(ldd % 8 == 0 && lda % 8 == 0 && ldd >= N && lda >= K);
     DIDI_CHECK_ARG(al16(dC_hi) && al16(dC_lo) && al16(A_hi) && al16(A_lo) && al16(dW) && al16(workspace));
     GemmParams p{};
@@ -2187,7 +2197,7 @@ extern "C" int didi_gemm_wgrad(const uint16_t* dC_hi, const uint16_t* dC_lo, int
     if (rc != DIDI_OK) return rc;
     p.lda = ldd; p.ldw = lda; p.act = DIDI_ACT_NONE;
     p.C_f32 = reinterpret_cast<float*>(workspace); p.ldc = K;
-    p.k_split = cdiv(M / 128, ks) * 128;
+    p.k_split = kc;
     p.tiles_m = cdiv(N, 256); p.tiles_n = cdiv(K, BBN);
     hipStream_t st = as_stream(stream);
     const dim3 grid(p.tiles_m * p.tiles_n, ks);

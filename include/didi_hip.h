@@ -597,8 +597,8 @@ int didi_split_both(const float* src, int R, int C, int ldo, uint16_t* t_hi, uin
  * LDS with transposing reads, so neither dC^T nor A^T is ever written (the two transposing passes per Linear that the
  * didi_gemm_small route needs).  fp32 result, dense [N, K]; split-K over the rows through `workspace`
  * (didi_gemm_wgrad_workspace_bytes(M, N, K, precision) bytes, 16-byte aligned; 0 = this shape / precision is not supported and
- * didi_gemm_wgrad returns DIDI_ERR_UNSUPPORTED: BF16X3, FP16X2 (dC rounded to its hi plane, A exact), FP16X3; M % 128 == 0,
- * M >= 8192; N >= 512, K >= 192, both % 8 == 0; at most 127 output tiles of 256 x 192).  ldd, lda % 8 == 0, planes 16-byte aligned. */
+ * didi_gemm_wgrad returns DIDI_ERR_UNSUPPORTED: BF16X3, FP16X2 (dC rounded to its hi plane, A exact), FP16X3; M % 32 == 0,
+ * M >= 8192; N >= 512, K >= 192, both % 8 == 0; at most 127 output tiles of 256 x 192 and at most half the device's CUs).  ldd, lda % 8 == 0, planes 16-byte aligned. */
 size_t didi_gemm_wgrad_workspace_bytes(int M, int N, int K, int precision);
 /* The input gradient of nn.Linear, dA [M, lda] = dC [M, N] W [N, K] (+ R_f32 [M, ldr], nullable: the gradient arriving over a skip
  * connection; torch: mm(dC, W)), with W's planes as the FORWARD holds them ([N, ldw] row-major: the contraction runs over W's rows,

@@ -282,7 +282,8 @@ def test_gemm_split_k_on_the_big_tile(ops, M, N, K, precision):
     a, w, bias = rnd(M, K, seed=47), rnd(N, K, seed=48, scale=0.05), rnd(N, seed=49)
     pd = PD[precision]
     ws = lib.didi_gemm_small_workspace_bytes(M, N, K, ops.PRECISIONS[precision])
-    assert ws > 0 and ws % (M * N * 4) == 0 and ws // (M * N * 4) >= 256 // (((M + 255) // 256) * (N // 192)) - 1
+    tiles = ((M + 255) // 256) * (N // 192)
+    assert ws > 0 and ws % (M * N * 4) == 0 and 192 < ws // (M * N * 4) * tiles <= 256  # one workgroup per CU: everything in ONE round
     a_hi, a_lo = ops.split(a.cuda(), dtype=pd)
     w_hi, w_lo = ops.split(w.cuda(), dtype=pd)
     _, _, c = ops.gemm(a_hi, a_lo, w_hi, w_lo, bias=bias.cuda(), precision=precision, out_f32=True, out_planes=False, small=())
@@ -342,7 +343,7 @@ def test_gemm_wgrad_limits(ops):
     assert not ops.wgrad_supported(16384, 768, 768, "fp16")      # one-product precisions keep the transposing route
     assert not ops.wgrad_supported(16384, 8008, 768, "bf16x3")   # 128 output tiles fill the chip without a split
     assert not ops.wgrad_supported(16384, 768, 100, "bf16x3")
-    assert not ops.wgrad_supported(16400, 768, 768, "bf16x3")    # rows not a multiple of 128
+    assert not ops.wgrad_supported(16400, 768, 768, "bf16x3")    # rows not a multiple of the 32-row K-tile
     assert not ops.dgrad_supported(1024, 768, 768, "bf16x3")     # too few rows for the 256-row tile to pay
     assert not ops.dgrad_supported(16384, 8008, 768, "bf16x3")   # contraction not a multiple of the K-step (the classifier)
     assert not ops.dgrad_supported(16384, 768, 768, "bf16")

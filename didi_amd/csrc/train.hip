@@ -299,8 +299,11 @@ __global__ void __launch_bounds__(256) transpose_split_kernel(const float* src, 
 // The same pass with 16-byte loads and 8-byte stores (C % 4 == 0, which every caller's shapes satisfy; the kernel above stays as the
 // general form): thread t loads columns 4 (t & 15) .. + 3 of rows (t >> 4) + 16 j, and stores rows-of-the-source 4 (t & 15) .. + 3 as
 // four consecutive columns of output row (t >> 4) + 16 j.  2.9 -> ~4 TB/s of the pass's 8 bytes per element.
+// drop_p > 0: src is a gradient arriving at a hidden-dropout site; its mask (dropout_add_kernel's: word e & 3 of
+// Philox4x32-10(offset + e / 4, seed) for element e = r C + c) is applied as the values are read, so the backward needs no pass of its own
 __global__ void __launch_bounds__(256) transpose_split_kernel_v4(const float* src, int R, int C, int ldo, u16* hi, u16* lo, int f16,
-                                                                 float* partial, u16* plain_hi = nullptr, u16* plain_lo = nullptr) {
+                                                                 float* partial, u16* plain_hi = nullptr, u16* plain_lo = nullptr,
+                                                                 float drop_p = 0.f, uint64_t drop_seed = 0, uint64_t drop_offset = 0) {
     __shared__ float tile[64][65];
     __shared__ float red[16][64];
     if (f16) f16_saturate_mode();
@@ -313,6 +316,16 @@ __global__ void __launch_bounds__(256) transpose_split_kernel_v4(const float* sr
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < R && c < C) {
             v = *reinterpret_cast<const float4*>(src + (size_t)r * C + c);  // C % 4 == 0: c + 3 < C too
+            if (drop_p > 0.f) {
+                const uint32_t thr = (uint32_t)fminf(drop_p * 4294967296.0f, 4294967040.0f);
+                const float inv_keep = 1.0f / (1.0f - drop_p);
+                uint32_t w[4];
+                philox4x32_10(drop_offset + ((size_t)r * C + c) / 4, drop_seed, w);
+                v.x = w[0] < thr ? 0.f : v.x * inv_keep;
+                v.y = w[1] < thr ? 0.f : v.y * inv_keep;
+                v.z = w[2] < thr ? 0.f : v.z * inv_keep;
+                v.w = w[3] < thr ? 0.f : v.w * inv_keep;
+            }
             if (plain_hi) {  // the un-transposed planes from the same read (the dgrad operand of linear_backward)
                 const float pv[4] = {v.x, v.y, v.z, v.w};
                 uint2 ph, pl;
@@ -384,8 +397,8 @@ extern "C" int didi_transpose_split_colsum(const float* src, int R, int C, int l
 
 // transposed planes + un-transposed planes (+ column sums when colsum != NULL) of one fp32 matrix in ONE pass: what linear_backward
 // needs of dC (dgrad reads dC, wgrad dC^T, the bias gradient its column sums).  C % 4 == 0.
-extern "C" int didi_split_both(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
-                               int plane_format, float* colsum, void* workspace, void* stream) {
+static int split_both_impl(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
+                           int plane_format, float* colsum, void* workspace, float drop_p, uint64_t drop_seed, uint64_t drop_offset, void* stream) {
     DIDI_CHECK_ARG(src && p_hi && R > 0 && C > 0 && ldo >= R && ldo == (R + 7) / 8 * 8 && (!colsum || workspace) && (t_hi || !t_lo));
     DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
     if (!transpose_v4_ok(src, C, ldo, t_hi, t_lo) || reinterpret_cast<uintptr_t>(p_hi) % 8 != 0 || reinterpret_cast<uintptr_t>(p_lo) % 8 != 0)
@@ -393,13 +406,24 @@ extern "C" int didi_split_both(const float* src, int R, int C, int ldo, uint16_t
     const int nb = cdiv(ldo, 64);
     hipStream_t st = as_stream(stream);
     transpose_split_kernel_v4<<<dim3(cdiv(C, 64), nb), 256, 0, st>>>(src, R, C, ldo, t_hi, t_lo, plane_format == DIDI_FMT_FP16,
-                                                                      colsum ? reinterpret_cast<float*>(workspace) : nullptr, p_hi, p_lo);
+                                                                      colsum ? reinterpret_cast<float*>(workspace) : nullptr, p_hi, p_lo, drop_p, drop_seed,
+                                                                      drop_offset);
     DIDI_LAUNCH_CHECK();
     if (colsum) {
         partial_rows_sum_kernel<<<cdiv(C, 64), 256, 0, st>>>(reinterpret_cast<const float*>(workspace), nb, C, C, colsum, nullptr);
         DIDI_LAUNCH_CHECK();
     }
     return DIDI_OK;
+}
+
+extern "C" int didi_split_both(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
+                               int plane_format, float* colsum, void* workspace, void* stream) {
+    return split_both_impl(src, R, C, ldo, t_hi, t_lo, p_hi, p_lo, plane_format, colsum, workspace, 0.f, 0, 0, stream);
+}
+extern "C" int didi_split_both_dropout(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
+                                       int plane_format, float* colsum, void* workspace, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
+    DIDI_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+    return split_both_impl(src, R, C, ldo, t_hi, t_lo, p_hi, p_lo, plane_format, colsum, workspace, drop_p, seed, offset, stream);
 }
 
 // ------------------------------------------------------------------ elementwise backward pieces

@@ -332,9 +332,9 @@ def transpose_split_colsum(x, dtype=torch.bfloat16):
     return hi, lo, out
 
 
-def split_both(x, dtype=torch.bfloat16, colsum=True, transposed=True):
+def split_both(x, dtype=torch.bfloat16, colsum=True, transposed=True, drop=None):
     """fp32 [R, C] -> (planes of x [R, C], planes of x^T [C, R8] (None, None without ``transposed``), column sums or None) in one
-    pass (C % 4 == 0)."""
+    pass (C % 4 == 0).  ``drop`` = (p, seed, offset): everything is taken of dropout(x) under ``dropout_add``'s mask."""
     x = _f32c(x)
     R, Cc = x.shape
     ldo = (R + 7) // 8 * 8
@@ -344,8 +344,13 @@ def split_both(x, dtype=torch.bfloat16, colsum=True, transposed=True):
     t_lo = torch.empty_like(t_hi) if transposed else None
     out = torch.empty(Cc, dtype=torch.float32, device=x.device) if colsum else None
     ws = torch.empty(lib.didi_transpose_split_colsum_bytes(R, Cc), dtype=torch.uint8, device=x.device) if colsum else None
-    _lib.check(lib.didi_split_both(x.data_ptr(), R, Cc, ldo, _lib.ptr(t_hi), _lib.ptr(t_lo), p_hi.data_ptr(), p_lo.data_ptr(), _fmt(dtype),
-                                   _lib.ptr(out), _lib.ptr(ws), _lib.current_stream()), "split_both")
+    if drop is not None and drop[0] > 0:
+        _lib.check(lib.didi_split_both_dropout(x.data_ptr(), R, Cc, ldo, _lib.ptr(t_hi), _lib.ptr(t_lo), p_hi.data_ptr(), p_lo.data_ptr(), _fmt(dtype),
+                                               _lib.ptr(out), _lib.ptr(ws), float(drop[0]), int(drop[1]), int(drop[2]), _lib.current_stream()),
+                   "split_both_dropout")
+    else:
+        _lib.check(lib.didi_split_both(x.data_ptr(), R, Cc, ldo, _lib.ptr(t_hi), _lib.ptr(t_lo), p_hi.data_ptr(), p_lo.data_ptr(), _fmt(dtype),
+                                       _lib.ptr(out), _lib.ptr(ws), _lib.current_stream()), "split_both")
     return (p_hi, p_lo), (t_hi, t_lo), out
 
 
@@ -388,22 +393,26 @@ def gemm_dgrad(dc_hi, dc_lo, w_hi, w_lo, precision="bf16x3", residual=None):
     return dA
 
 
-def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, residual=None, fault=None, A_planes=None, W_planes=None):
+def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, residual=None, fault=None, A_planes=None, W_planes=None, dC_drop=None):
     """Backward of C = A W^T + b (nn.Linear): dC [M,N], A [M,K], W [N,K] fp32 -> (dA [M,K] (+ residual), dW [N,K], db [N] or None).
     dgrad is a didi_gemm launch on the transposed weight planes; wgrad is didi_gemm_wgrad on the planes of dC and of A as they are
     (``A_planes``: the (hi, lo) the forward multiplied with -- passed, nothing of A is re-read in fp32; A may then be None) where that
     form applies, else a didi_gemm launch on transposed operand planes; with ``W_planes`` (the forward's weight planes) dgrad is
     didi_gemm_dgrad on them where that form applies (no transposed copy of W); db comes out of the pass that splits dC.
-    ``residual`` fp32 [M,K]: added to dA in the dgrad GEMM's epilogue (the gradient of a skip connection joining there)."""
+    ``residual`` fp32 [M,K]: added to dA in the dgrad GEMM's epilogue (the gradient of a skip connection joining there).
+    ``dC_drop`` = (p, seed, offset): the Linear's output went through hidden dropout; dC is the gradient BEHIND it, and the mask is
+    applied in the pass that splits dC (or by ``dropout_add`` where that pass is not the one-read form)."""
     pd = plane_dtype(precision)
     dC, W = _f32c(dC), _f32c(W)
     M, N = dC.shape
     K = W.shape[1]
     tn = wgrad_supported(M, N, K, precision) and (A_planes is not None or A is not None)
+    if dC_drop is not None and dC_drop[0] > 0 and not tn:
+        dC, dC_drop = dropout_add(dC, None, *dC_drop), None
     one_pass = N % 8 == 0 and (need_dA or tn)  # dC's planes, its transposed planes and its column sums from one read of dC
     dct = None
     if tn:
-        (dc_hi, dc_lo), _, db1 = split_both(dC, dtype=pd, colsum=bias, transposed=False)
+        (dc_hi, dc_lo), _, db1 = split_both(dC, dtype=pd, colsum=bias, transposed=False, drop=dC_drop)
         a_hi, a_lo = A_planes if A_planes is not None else split(_f32c(A), dtype=pd)
     elif one_pass:
         (dc_hi, dc_lo), dct, db1 = split_both(dC, dtype=pd, colsum=bias)

@@ -214,9 +214,9 @@ class DiDiTrainer:
     def _linear(self, w, a_hi, a_lo, **kw):
         return ops.gemm(a_hi, a_lo, w.hi, w.lo, bias=w.b, precision=self.precision, out_f32=True, fault=self.fault, **kw)
 
-    def _linear_bwd(self, dC, A, w, residual=None, need_dA=True, A_planes=None):
+    def _linear_bwd(self, dC, A, w, residual=None, need_dA=True, A_planes=None, dC_drop=None):
         return ops.linear_backward(dC, A, w.w, precision=self.precision, residual=residual, need_dA=need_dA, fault=self.fault, A_planes=A_planes,
-                                   W_planes=(w.hi, w.lo))
+                                   W_planes=(w.hi, w.lo), dC_drop=dC_drop)
 
     def check_fault(self, what="training step"):
         """fp16 planes only: wait for the stream and raise if a GEMM of the step wrote a value beyond fp16's range into a plane
@@ -402,14 +402,14 @@ class DiDiTrainer:
 
             ds3, dg, db = ops.layernorm_backward(dh, s["s3"], P[ln["ln3"] + ".weight"], eps)
             put(ln["ln3"], dg, db)
-            df, dW, dbias = self._linear_bwd(drop(ds3, None, s["off_down"]) if ph > 0 else ds3, s["f"], L["down"], A_planes=s["fp"])
+            df, dW, dbias = self._linear_bwd(ds3, s["f"], L["down"], A_planes=s["fp"], dC_drop=(ph, dseed, s["off_down"]))
             put(ln["down"], dW, dbias)
             du = ops.act_backward("gelu", df, s["u"])
             dh2, dW, dbias = self._linear_bwd(du, s["h2"], L["up"], residual=ds3, A_planes=s["h2p"])  # + the skip connection around the FFN
             put(ln["up"], dW, dbias)
             ds2, dg, db = ops.layernorm_backward(dh2, s["s2"], P[ln["ln2"] + ".weight"], eps)
             put(ln["ln2"], dg, db)
-            dcatt, dW, dbias = self._linear_bwd(drop(ds2, None, s["off_co"]) if ph > 0 else ds2, s["catt"], L["co"], A_planes=s["cattp"])
+            dcatt, dW, dbias = self._linear_bwd(ds2, s["catt"], L["co"], A_planes=s["cattp"], dC_drop=(ph, dseed, s["off_co"]))
             put(ln["co"], dW, dbias)
             ckv = s["ckv"].view(B, Cn, 2 * H)
             dckv = torch.empty_like(ckv)
@@ -425,7 +425,7 @@ class DiDiTrainer:
                 dctx = dctx_l  # accumulated over the layers in the dgrad epilogue
             ds1, dg, db = ops.layernorm_backward(dh1, s["s1"], P[ln["ln1"] + ".weight"], eps)
             put(ln["ln1"], dg, db)
-            datt, dW, dbias = self._linear_bwd(drop(ds1, None, s["off_o"]) if ph > 0 else ds1, s["att"], L["o"], A_planes=s["attp"])
+            datt, dW, dbias = self._linear_bwd(ds1, s["att"], L["o"], A_planes=s["attp"], dC_drop=(ph, dseed, s["off_o"]))
             put(ln["o"], dW, dbias)
             qkv = s["qkv"].view(B, S, 3 * H)
             dqkv = torch.empty_like(qkv)

@@ -591,6 +591,11 @@ int didi_transpose_split_colsum(const float* src, int R, int C, int ldo, uint16_
 /* t_hi == NULL (ABI 7): no transposed planes -- what is left of the pass when the weight gradient goes through didi_gemm_wgrad. */
 int didi_split_both(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
                     int plane_format, float* colsum, void* workspace, void* stream);
+/* didi_split_both on dropout(src): src is a gradient arriving at a hidden-dropout site (BertSelfOutput / BertOutput,
+ * HF:models/bert/modeling_bert.py:293,351); the mask of didi_dropout_add (same seed / offset) is applied as the values are read,
+ * so the backward of that dropout is not a pass of its own. */
+int didi_split_both_dropout(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
+                            int plane_format, float* colsum, void* workspace, float drop_p, uint64_t seed, uint64_t offset, void* stream);
 /* The weight gradient of nn.Linear, dW [N, K] = dC^T A (what `loss.backward()` of src/diffusion/model.py:200-243 computes for every
  * Linear of the decoder; torch: mm(dC.t(), A)), from the split planes of dC [M, ldd] and A [M, lda] AS THEY LIE IN MEMORY: the
  * contraction runs over the ROWS of both, the kernel stages [32 rows][256 | 192 columns] tiles and takes its MFMA fragments out of

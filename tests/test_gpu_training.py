@@ -165,6 +165,15 @@ def test_split_both_equals_the_three_passes(dtype):
     u_hi, u_lo, want_cs = ops.transpose_split_colsum(x, dtype=dtype)
     assert torch.equal(p_hi, w_hi) and torch.equal(p_lo, w_lo) and torch.equal(t_hi, u_hi) and torch.equal(t_lo, u_lo) and torch.equal(cs, want_cs)
     assert ops.split_both(x, dtype=dtype, colsum=False)[2] is None
+    # without the transposed planes (the weight gradient reads dC as it lies), and of dropout(x): the mask of dropout_add, applied on the read
+    (q_hi, q_lo), (n_hi, n_lo), cs2 = ops.split_both(x, dtype=dtype, transposed=False)
+    assert n_hi is None and n_lo is None and torch.equal(q_hi, w_hi) and torch.equal(q_lo, w_lo) and torch.equal(cs2, want_cs)
+    seed, off = 1234567, 5 << 34
+    xd = ops.dropout_add(x, None, 0.1, seed, off)
+    assert 0.05 < float((xd == 0).float().mean()) < 0.15
+    (d_hi, d_lo), (dt_hi, dt_lo), dcs = ops.split_both(x, dtype=dtype, drop=(0.1, seed, off))
+    (e_hi, e_lo), (et_hi, et_lo), ecs = ops.split_both(xd, dtype=dtype)
+    assert torch.equal(d_hi, e_hi) and torch.equal(d_lo, e_lo) and torch.equal(dt_hi, et_hi) and torch.equal(dt_lo, et_lo) and torch.equal(dcs, ecs)
 
 
 def test_transpose_split_and_colsum():

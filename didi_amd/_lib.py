@@ -188,8 +188,8 @@ SYMBOLS = [
     ("didi_transpose_split_colsum_bytes", C.c_size_t, [C.c_int, C.c_int]),
     ("didi_transpose_split_colsum", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_void_p]),
-    ("didi_split_both_dropout", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
-                                          C.c_void_p, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
+    ("didi_split_both_ex", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
     ("didi_gemm_wgrad_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("didi_gemm_wgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
@@ -209,6 +209,8 @@ SYMBOLS = [
     ("didi_attention_train_forward", C.c_int, [C.c_void_p, C.c_void_p]),
     ("didi_attention_train_backward", C.c_int, [C.c_void_p, C.c_void_p]),
     ("didi_dropout_add", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    ("didi_dropout_add_layernorm", C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     ("didi_adamw_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     ("didi_sumsq_accumulate", C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -147,6 +147,60 @@ extern "C" int didi_layernorm(const float* x, const float* gamma, const float* b
     return DIDI_OK;
 }
 
+// Training forward of BertSelfOutput / BertOutput with hidden dropout on: s = residual + dropout(x) (didi_dropout_add's mask and
+// arithmetic), s kept for the backward, LayerNorm(s) out -- one read of x and of the residual instead of a dropout pass that writes s
+// and a LayerNorm pass that reads it back.
+template <int MAXV>
+__global__ void __launch_bounds__(256) dropout_add_layernorm_kernel(const float* x, const float* residual, float p, uint64_t seed, uint64_t offset,
+                                                                    float* sum_out, const float* gamma, const float* beta, float eps, int M, int H,
+                                                                    u16* y_hi, u16* y_lo, float* y_f32, int f16) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const size_t row_off = (size_t)m * H;
+    const uint32_t thr = (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f);
+    const float inv_keep = 1.0f / (1.0f - p);
+    float v[MAXV][4];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c * 4 < H) {
+            float4 t = reinterpret_cast<const float4*>(x + row_off)[c];
+            const float4 r = reinterpret_cast<const float4*>(residual + row_off)[c];
+            uint32_t w[4];
+            philox4x32_10(offset + row_off / 4 + c, seed, w);
+            t.x = w[0] < thr ? 0.f : t.x * inv_keep;
+            t.y = w[1] < thr ? 0.f : t.y * inv_keep;
+            t.z = w[2] < thr ? 0.f : t.z * inv_keep;
+            t.w = w[3] < thr ? 0.f : t.w * inv_keep;
+            t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+            reinterpret_cast<float4*>(sum_out + row_off)[c] = t;
+            v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
+        } else {
+            v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+        }
+    }
+    ln_row_store<MAXV>(v, lane, H, row_off, gamma, beta, eps, y_hi, y_lo, y_f32, f16);
+}
+
+extern "C" int didi_dropout_add_layernorm(const float* x, const float* residual, float p, uint64_t seed, uint64_t offset, float* sum_out,
+                                          const float* gamma, const float* beta, float eps, int M, int H, uint16_t* y_hi, uint16_t* y_lo,
+                                          float* y_f32, int plane_format, void* stream) {
+    DIDI_CHECK_ARG(x && residual && sum_out && gamma && beta && (y_hi || y_f32) && M >= 0 && H > 0 && p >= 0.f && p < 1.f);
+    DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
+    const int f16 = plane_format == DIDI_FMT_FP16;
+    DIDI_CHECK_ARG(!(y_lo && !y_hi));
+    if (H % 4 != 0 || H > 1280) return DIDI_ERR_UNSUPPORTED;
+    if (M == 0) return DIDI_OK;
+    const int grid = cdiv(M, 4);
+    hipStream_t st = as_stream(stream);
+    if (H <= 256) dropout_add_layernorm_kernel<1><<<grid, 256, 0, st>>>(x, residual, p, seed, offset, sum_out, gamma, beta, eps, M, H, y_hi, y_lo, y_f32, f16);
+    else if (H <= 768) dropout_add_layernorm_kernel<3><<<grid, 256, 0, st>>>(x, residual, p, seed, offset, sum_out, gamma, beta, eps, M, H, y_hi, y_lo, y_f32, f16);
+    else dropout_add_layernorm_kernel<5><<<grid, 256, 0, st>>>(x, residual, p, seed, offset, sum_out, gamma, beta, eps, M, H, y_hi, y_lo, y_f32, f16);
+    DIDI_LAUNCH_CHECK();
+    return DIDI_OK;
+}
+
 // ------------------------------------------------------------------ T5LayerNorm (RMS norm) and the gated-FFN product
 template <int MAXV>
 __global__ void __launch_bounds__(256) rmsnorm_kernel(const float* x, const float* gamma, float eps, int M, int H, u16* y_hi,

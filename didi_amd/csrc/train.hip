@@ -296,6 +296,10 @@ __global__ void __launch_bounds__(256) transpose_split_kernel(const float* src, 
     }
 }
 
+// d/dx of the exact-erf GELU: Phi(x) + x phi(x)
+__device__ __forceinline__ float gelu_grad(float v) {
+    return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+}
 // The same pass with 16-byte loads and 8-byte stores (C % 4 == 0, which every caller's shapes satisfy; the kernel above stays as the
 // general form): thread t loads columns 4 (t & 15) .. + 3 of rows (t >> 4) + 16 j, and stores rows-of-the-source 4 (t & 15) .. + 3 as
 // four consecutive columns of output row (t >> 4) + 16 j.  2.9 -> ~4 TB/s of the pass's 8 bytes per element.
@@ -303,7 +307,8 @@ __global__ void __launch_bounds__(256) transpose_split_kernel(const float* src, 
 // Philox4x32-10(offset + e / 4, seed) for element e = r C + c) is applied as the values are read, so the backward needs no pass of its own
 __global__ void __launch_bounds__(256) transpose_split_kernel_v4(const float* src, int R, int C, int ldo, u16* hi, u16* lo, int f16,
                                                                  float* partial, u16* plain_hi = nullptr, u16* plain_lo = nullptr,
-                                                                 float drop_p = 0.f, uint64_t drop_seed = 0, uint64_t drop_offset = 0) {
+                                                                 float drop_p = 0.f, uint64_t drop_seed = 0, uint64_t drop_offset = 0,
+                                                                 const float* gelu_u = nullptr) {
     __shared__ float tile[64][65];
     __shared__ float red[16][64];
     if (f16) f16_saturate_mode();
@@ -316,6 +321,10 @@ __global__ void __launch_bounds__(256) transpose_split_kernel_v4(const float* sr
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < R && c < C) {
             v = *reinterpret_cast<const float4*>(src + (size_t)r * C + c);  // C % 4 == 0: c + 3 < C too
+            if (gelu_u) {  // src is the gradient behind a GELU whose pre-activation is gelu_u: gelu_backward_kernel's factor, on the read
+                const float4 u = *reinterpret_cast<const float4*>(gelu_u + (size_t)r * C + c);
+                v.x *= gelu_grad(u.x); v.y *= gelu_grad(u.y); v.z *= gelu_grad(u.z); v.w *= gelu_grad(u.w);
+            }
             if (drop_p > 0.f) {
                 const uint32_t thr = (uint32_t)fminf(drop_p * 4294967296.0f, 4294967040.0f);
                 const float inv_keep = 1.0f / (1.0f - drop_p);
@@ -398,7 +407,8 @@ extern "C" int didi_transpose_split_colsum(const float* src, int R, int C, int l
 // transposed planes + un-transposed planes (+ column sums when colsum != NULL) of one fp32 matrix in ONE pass: what linear_backward
 // needs of dC (dgrad reads dC, wgrad dC^T, the bias gradient its column sums).  C % 4 == 0.
 static int split_both_impl(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
-                           int plane_format, float* colsum, void* workspace, float drop_p, uint64_t drop_seed, uint64_t drop_offset, void* stream) {
+                           int plane_format, float* colsum, void* workspace, const float* gelu_u, float drop_p, uint64_t drop_seed, uint64_t drop_offset,
+                           void* stream) {
     DIDI_CHECK_ARG(src && p_hi && R > 0 && C > 0 && ldo >= R && ldo == (R + 7) / 8 * 8 && (!colsum || workspace) && (t_hi || !t_lo));
     DIDI_CHECK_ARG(plane_format == DIDI_FMT_BF16 || plane_format == DIDI_FMT_FP16);
     if (!transpose_v4_ok(src, C, ldo, t_hi, t_lo) || reinterpret_cast<uintptr_t>(p_hi) % 8 != 0 || reinterpret_cast<uintptr_t>(p_lo) % 8 != 0)
@@ -407,7 +417,7 @@ static int split_both_impl(const float* src, int R, int C, int ldo, uint16_t* t_
     hipStream_t st = as_stream(stream);
     transpose_split_kernel_v4<<<dim3(cdiv(C, 64), nb), 256, 0, st>>>(src, R, C, ldo, t_hi, t_lo, plane_format == DIDI_FMT_FP16,
                                                                       colsum ? reinterpret_cast<float*>(workspace) : nullptr, p_hi, p_lo, drop_p, drop_seed,
-                                                                      drop_offset);
+                                                                      drop_offset, gelu_u);
     DIDI_LAUNCH_CHECK();
     if (colsum) {
         partial_rows_sum_kernel<<<cdiv(C, 64), 256, 0, st>>>(reinterpret_cast<const float*>(workspace), nb, C, C, colsum, nullptr);
@@ -418,12 +428,13 @@ static int split_both_impl(const float* src, int R, int C, int ldo, uint16_t* t_
 
 extern "C" int didi_split_both(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
                                int plane_format, float* colsum, void* workspace, void* stream) {
-    return split_both_impl(src, R, C, ldo, t_hi, t_lo, p_hi, p_lo, plane_format, colsum, workspace, 0.f, 0, 0, stream);
+    return split_both_impl(src, R, C, ldo, t_hi, t_lo, p_hi, p_lo, plane_format, colsum, workspace, nullptr, 0.f, 0, 0, stream);
 }
-extern "C" int didi_split_both_dropout(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
-                                       int plane_format, float* colsum, void* workspace, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
-    DIDI_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
-    return split_both_impl(src, R, C, ldo, t_hi, t_lo, p_hi, p_lo, plane_format, colsum, workspace, drop_p, seed, offset, stream);
+extern "C" int didi_split_both_ex(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
+                                  int plane_format, float* colsum, void* workspace, const float* gelu_u, float drop_p, uint64_t seed, uint64_t offset,
+                                  void* stream) {
+    DIDI_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && reinterpret_cast<uintptr_t>(gelu_u) % 16 == 0);
+    return split_both_impl(src, R, C, ldo, t_hi, t_lo, p_hi, p_lo, plane_format, colsum, workspace, gelu_u, drop_p, seed, offset, stream);
 }
 
 // ------------------------------------------------------------------ elementwise backward pieces
@@ -432,8 +443,7 @@ __global__ void __launch_bounds__(256) gelu_backward_kernel(const float* df, con
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const float4 g = reinterpret_cast<const float4*>(df)[i], x = reinterpret_cast<const float4*>(u)[i];
-    auto d = [](float v) { return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v); };
-    reinterpret_cast<float4*>(du)[i] = make_float4(g.x * d(x.x), g.y * d(x.y), g.z * d(x.z), g.w * d(x.w));
+    reinterpret_cast<float4*>(du)[i] = make_float4(g.x * gelu_grad(x.x), g.y * gelu_grad(x.y), g.z * gelu_grad(x.z), g.w * gelu_grad(x.w));
 }
 __global__ void __launch_bounds__(256) tanh_backward_kernel(const float* dy, const float* y, size_t n4, float* dz) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -332,9 +332,10 @@ def transpose_split_colsum(x, dtype=torch.bfloat16):
     return hi, lo, out
 
 
-def split_both(x, dtype=torch.bfloat16, colsum=True, transposed=True, drop=None):
+def split_both(x, dtype=torch.bfloat16, colsum=True, transposed=True, drop=None, gelu_u=None):
     """fp32 [R, C] -> (planes of x [R, C], planes of x^T [C, R8] (None, None without ``transposed``), column sums or None) in one
-    pass (C % 4 == 0).  ``drop`` = (p, seed, offset): everything is taken of dropout(x) under ``dropout_add``'s mask."""
+    pass (C % 4 == 0).  ``drop`` = (p, seed, offset): everything is taken of dropout(x) under ``dropout_add``'s mask; ``gelu_u``
+    fp32 [R, C]: of x * gelu'(gelu_u) (``act_backward("gelu", x, gelu_u)``)."""
     x = _f32c(x)
     R, Cc = x.shape
     ldo = (R + 7) // 8 * 8
@@ -344,10 +345,14 @@ def split_both(x, dtype=torch.bfloat16, colsum=True, transposed=True, drop=None)
     t_lo = torch.empty_like(t_hi) if transposed else None
     out = torch.empty(Cc, dtype=torch.float32, device=x.device) if colsum else None
     ws = torch.empty(lib.didi_transpose_split_colsum_bytes(R, Cc), dtype=torch.uint8, device=x.device) if colsum else None
-    if drop is not None and drop[0] > 0:
-        _lib.check(lib.didi_split_both_dropout(x.data_ptr(), R, Cc, ldo, _lib.ptr(t_hi), _lib.ptr(t_lo), p_hi.data_ptr(), p_lo.data_ptr(), _fmt(dtype),
-                                               _lib.ptr(out), _lib.ptr(ws), float(drop[0]), int(drop[1]), int(drop[2]), _lib.current_stream()),
-                   "split_both_dropout")
+    if (drop is not None and drop[0] > 0) or gelu_u is not None:
+        drop = drop if drop is not None else (0.0, 0, 0)
+        if gelu_u is not None:
+            gelu_u = _f32c(gelu_u)
+            assert gelu_u.shape == x.shape
+        _lib.check(lib.didi_split_both_ex(x.data_ptr(), R, Cc, ldo, _lib.ptr(t_hi), _lib.ptr(t_lo), p_hi.data_ptr(), p_lo.data_ptr(), _fmt(dtype),
+                                          _lib.ptr(out), _lib.ptr(ws), _lib.ptr(gelu_u), float(drop[0]), int(drop[1]), int(drop[2]),
+                                          _lib.current_stream()), "split_both_ex")
     else:
         _lib.check(lib.didi_split_both(x.data_ptr(), R, Cc, ldo, _lib.ptr(t_hi), _lib.ptr(t_lo), p_hi.data_ptr(), p_lo.data_ptr(), _fmt(dtype),
                                        _lib.ptr(out), _lib.ptr(ws), _lib.current_stream()), "split_both")
@@ -393,7 +398,7 @@ def gemm_dgrad(dc_hi, dc_lo, w_hi, w_lo, precision="bf16x3", residual=None):
     return dA
 
 
-def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, residual=None, fault=None, A_planes=None, W_planes=None, dC_drop=None):
+def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, residual=None, fault=None, A_planes=None, W_planes=None, dC_drop=None, dC_gelu_u=None):
     """Backward of C = A W^T + b (nn.Linear): dC [M,N], A [M,K], W [N,K] fp32 -> (dA [M,K] (+ residual), dW [N,K], db [N] or None).
     dgrad is a didi_gemm launch on the transposed weight planes; wgrad is didi_gemm_wgrad on the planes of dC and of A as they are
     (``A_planes``: the (hi, lo) the forward multiplied with -- passed, nothing of A is re-read in fp32; A may then be None) where that
@@ -401,18 +406,21 @@ def linear_backward(dC, A, W, precision="bf16x3", bias=True, need_dA=True, resid
     didi_gemm_dgrad on them where that form applies (no transposed copy of W); db comes out of the pass that splits dC.
     ``residual`` fp32 [M,K]: added to dA in the dgrad GEMM's epilogue (the gradient of a skip connection joining there).
     ``dC_drop`` = (p, seed, offset): the Linear's output went through hidden dropout; dC is the gradient BEHIND it, and the mask is
-    applied in the pass that splits dC (or by ``dropout_add`` where that pass is not the one-read form)."""
+    applied in the pass that splits dC (or by ``dropout_add`` where that pass is not the one-read form).  ``dC_gelu_u`` fp32 [M,N]:
+    the Linear's output went through GELU with this pre-activation; likewise (or ``act_backward``)."""
     pd = plane_dtype(precision)
     dC, W = _f32c(dC), _f32c(W)
     M, N = dC.shape
     K = W.shape[1]
     tn = wgrad_supported(M, N, K, precision) and (A_planes is not None or A is not None)
+    if dC_gelu_u is not None and not tn:
+        dC, dC_gelu_u = act_backward("gelu", dC, dC_gelu_u), None
     if dC_drop is not None and dC_drop[0] > 0 and not tn:
         dC, dC_drop = dropout_add(dC, None, *dC_drop), None
     one_pass = N % 8 == 0 and (need_dA or tn)  # dC's planes, its transposed planes and its column sums from one read of dC
     dct = None
     if tn:
-        (dc_hi, dc_lo), _, db1 = split_both(dC, dtype=pd, colsum=bias, transposed=False, drop=dC_drop)
+        (dc_hi, dc_lo), _, db1 = split_both(dC, dtype=pd, colsum=bias, transposed=False, drop=dC_drop, gelu_u=dC_gelu_u)
         a_hi, a_lo = A_planes if A_planes is not None else split(_f32c(A), dtype=pd)
     elif one_pass:
         (dc_hi, dc_lo), dct, db1 = split_both(dC, dtype=pd, colsum=bias)
@@ -556,6 +564,20 @@ def dropout_add(x, residual, p, seed, offset):
     _lib.check(lib.didi_dropout_add(x.data_ptr(), _lib.ptr(r), x.numel(), float(p), int(seed), int(offset), out.data_ptr(),
                                     _lib.current_stream()), "dropout_add")
     return out
+
+
+def dropout_add_layernorm(x, residual, p, seed, offset, gamma, beta, eps, dtype=torch.bfloat16, f32=True):
+    """s = dropout_add(x, residual, ...) and layernorm(s) in one pass -> (hi, lo, y fp32 or None, s)."""
+    x, residual = _f32c(x), _f32c(residual)
+    assert x.shape == residual.shape
+    M, H = x.numel() // x.shape[-1], x.shape[-1]
+    s = torch.empty_like(x)
+    hi, lo = torch.empty_like(x, dtype=dtype), torch.empty_like(x, dtype=dtype)
+    y = torch.empty_like(x) if f32 else None
+    _lib.check(lib.didi_dropout_add_layernorm(x.data_ptr(), residual.data_ptr(), float(p), int(seed), int(offset), s.data_ptr(), gamma.data_ptr(),
+                                              beta.data_ptr(), eps, M, H, hi.data_ptr(), lo.data_ptr(), _lib.ptr(y), _fmt(dtype),
+                                              _lib.current_stream()), "dropout_add_layernorm")
+    return hi, lo, y, s
 
 
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gscale=None):

@@ -214,9 +214,9 @@ class DiDiTrainer:
     def _linear(self, w, a_hi, a_lo, **kw):
         return ops.gemm(a_hi, a_lo, w.hi, w.lo, bias=w.b, precision=self.precision, out_f32=True, fault=self.fault, **kw)
 
-    def _linear_bwd(self, dC, A, w, residual=None, need_dA=True, A_planes=None, dC_drop=None):
+    def _linear_bwd(self, dC, A, w, residual=None, need_dA=True, A_planes=None, dC_drop=None, dC_gelu_u=None):
         return ops.linear_backward(dC, A, w.w, precision=self.precision, residual=residual, need_dA=need_dA, fault=self.fault, A_planes=A_planes,
-                                   W_planes=(w.hi, w.lo), dC_drop=dC_drop)
+                                   W_planes=(w.hi, w.lo), dC_drop=dC_drop, dC_gelu_u=dC_gelu_u)
 
     def check_fault(self, what="training step"):
         """fp16 planes only: wait for the stream and raise if a GEMM of the step wrote a value beyond fp16's range into a plane
@@ -312,10 +312,10 @@ class DiDiTrainer:
             s["off_o"] = site()
             if ph > 0:  # BertSelfOutput: LayerNorm(dropout(dense(x)) + input)
                 _, _, y = self._linear(L["o"], a_hi, a_lo, out_planes=False)
-                s1 = drop(y, h, s["off_o"])
+                h_hi, h_lo, h1, s1 = ops.dropout_add_layernorm(y, h, ph, dseed, s["off_o"], P[ln["ln1"] + ".weight"], P[ln["ln1"] + ".bias"], eps, dtype=pd)
             else:
                 _, _, s1 = self._linear(L["o"], a_hi, a_lo, residual=h, out_planes=False)
-            h_hi, h_lo, h1 = ops.layernorm(s1, P[ln["ln1"] + ".weight"], P[ln["ln1"] + ".bias"], eps, f32=True, dtype=pd)
+                h_hi, h_lo, h1 = ops.layernorm(s1, P[ln["ln1"] + ".weight"], P[ln["ln1"] + ".bias"], eps, f32=True, dtype=pd)
             s["s1"], s["h1"], s["h1p"] = s1, h1, (h_hi, h_lo)
             _, _, cq = self._linear(L["cq"], h_hi, h_lo, out_planes=False)
             _, _, ckv = self._linear(L["ckv"], x_hi, x_lo, out_planes=False)
@@ -328,10 +328,10 @@ class DiDiTrainer:
             s["off_co"] = site()
             if ph > 0:
                 _, _, y = self._linear(L["co"], ca_hi, ca_lo, out_planes=False)
-                s2 = drop(y, h1, s["off_co"])
+                h_hi, h_lo, h2, s2 = ops.dropout_add_layernorm(y, h1, ph, dseed, s["off_co"], P[ln["ln2"] + ".weight"], P[ln["ln2"] + ".bias"], eps, dtype=pd)
             else:
                 _, _, s2 = self._linear(L["co"], ca_hi, ca_lo, residual=h1, out_planes=False)
-            h_hi, h_lo, h2 = ops.layernorm(s2, P[ln["ln2"] + ".weight"], P[ln["ln2"] + ".bias"], eps, f32=True, dtype=pd)
+                h_hi, h_lo, h2 = ops.layernorm(s2, P[ln["ln2"] + ".weight"], P[ln["ln2"] + ".bias"], eps, f32=True, dtype=pd)
             s["s2"], s["h2"], s["h2p"] = s2, h2, (h_hi, h_lo)
             _, _, u = self._linear(L["up"], h_hi, h_lo, out_planes=False)
             f_hi, f_lo, f_ = self._gelu_planes(u, H)
@@ -339,10 +339,10 @@ class DiDiTrainer:
             s["off_down"] = site()
             if ph > 0:
                 _, _, y = self._linear(L["down"], f_hi, f_lo, out_planes=False)
-                s3 = drop(y, h2, s["off_down"])
+                h_hi, h_lo, h, s3 = ops.dropout_add_layernorm(y, h2, ph, dseed, s["off_down"], P[ln["ln3"] + ".weight"], P[ln["ln3"] + ".bias"], eps, dtype=pd)
             else:
                 _, _, s3 = self._linear(L["down"], f_hi, f_lo, residual=h2, out_planes=False)
-            h_hi, h_lo, h = ops.layernorm(s3, P[ln["ln3"] + ".weight"], P[ln["ln3"] + ".bias"], eps, f32=True, dtype=pd)
+                h_hi, h_lo, h = ops.layernorm(s3, P[ln["ln3"] + ".weight"], P[ln["ln3"] + ".bias"], eps, f32=True, dtype=pd)
             s["s3"] = s3
             saved.append(s)
         x_0_hat = h.view(B, S, H)
@@ -404,8 +404,8 @@ class DiDiTrainer:
             put(ln["ln3"], dg, db)
             df, dW, dbias = self._linear_bwd(ds3, s["f"], L["down"], A_planes=s["fp"], dC_drop=(ph, dseed, s["off_down"]))
             put(ln["down"], dW, dbias)
-            du = ops.act_backward("gelu", df, s["u"])
-            dh2, dW, dbias = self._linear_bwd(du, s["h2"], L["up"], residual=ds3, A_planes=s["h2p"])  # + the skip connection around the FFN
+            # GELU's backward rides on the pass that splits the gradient; + the skip connection around the FFN
+            dh2, dW, dbias = self._linear_bwd(df, s["h2"], L["up"], residual=ds3, A_planes=s["h2p"], dC_gelu_u=s["u"])
             put(ln["up"], dW, dbias)
             ds2, dg, db = ops.layernorm_backward(dh2, s["s2"], P[ln["ln2"] + ".weight"], eps)
             put(ln["ln2"], dg, db)

@@ -591,11 +591,13 @@ int didi_transpose_split_colsum(const float* src, int R, int C, int ldo, uint16_
 /* t_hi == NULL (ABI 7): no transposed planes -- what is left of the pass when the weight gradient goes through didi_gemm_wgrad. */
 int didi_split_both(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
                     int plane_format, float* colsum, void* workspace, void* stream);
-/* didi_split_both on dropout(src): src is a gradient arriving at a hidden-dropout site (BertSelfOutput / BertOutput,
- * HF:models/bert/modeling_bert.py:293,351); the mask of didi_dropout_add (same seed / offset) is applied as the values are read,
- * so the backward of that dropout is not a pass of its own. */
-int didi_split_both_dropout(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
-                            int plane_format, float* colsum, void* workspace, float drop_p, uint64_t seed, uint64_t offset, void* stream);
+/* didi_split_both on a gradient that still has an elementwise backward in front of it, applied as the values are read so that it is
+ * not a pass of its own: gelu_u != NULL -- src is the gradient behind BertIntermediate's GELU (HF:models/bert/modeling_bert.py:335-336)
+ * and gelu_u [R, C] its pre-activation: src * gelu'(gelu_u), what didi_act_backward(DIDI_ACT_GELU) computes; drop_p > 0 -- src is a
+ * gradient arriving at a hidden-dropout site (BertSelfOutput / BertOutput, :293,351): the mask of didi_dropout_add (same seed / offset). */
+int didi_split_both_ex(const float* src, int R, int C, int ldo, uint16_t* t_hi, uint16_t* t_lo, uint16_t* p_hi, uint16_t* p_lo,
+                       int plane_format, float* colsum, void* workspace, const float* gelu_u, float drop_p, uint64_t seed, uint64_t offset,
+                       void* stream);
 /* The weight gradient of nn.Linear, dW [N, K] = dC^T A (what `loss.backward()` of src/diffusion/model.py:200-243 computes for every
  * Linear of the decoder; torch: mm(dC.t(), A)), from the split planes of dC [M, ldd] and A [M, lda] AS THEY LIE IN MEMORY: the
  * contraction runs over the ROWS of both, the kernel stages [32 rows][256 | 192 columns] tiles and takes its MFMA fragments out of
@@ -662,6 +664,12 @@ int didi_attention_train_backward(const didi_attn_train_args* a, void* stream);
  * out = x o mask / (1 - p) + residual (nullable); flat element e is dropped iff word (e & 3) of
  * Philox4x32-10(offset + e / 4, seed) < p 2^32.  Backward = the same call on the gradient with residual = NULL. n % 4 == 0. */
 int didi_dropout_add(const float* x, const float* residual, size_t n, float p, uint64_t seed, uint64_t offset, float* out, void* stream);
+/* The same followed by the block's LayerNorm in one pass (`LayerNorm(dropout(dense(x)) + input)`, HF:models/bert/modeling_bert.py:291-295,
+ * 349-353 in training mode): sum_out [M, H] = x o mask / (1 - p) + residual (kept: the LayerNorm backward's input), then didi_layernorm
+ * of it into y_hi / y_lo / y_f32.  H % 4 == 0, H <= 1280. */
+int didi_dropout_add_layernorm(const float* x, const float* residual, float p, uint64_t seed, uint64_t offset, float* sum_out,
+                               const float* gamma, const float* beta, float eps, int M, int H, uint16_t* y_hi, uint16_t* y_lo, float* y_f32,
+                               int plane_format, void* stream);
 /* torch.optim.AdamW step (src/diffusion/model.py:136-158: AdamW(lr = 1) x LambdaLR, so `lr` is the schedule's value) on one
  * parameter tensor, gradient pre-scaled by *gscale (device scalar or NULL: the clipping coefficient, configs/train.yaml:45). */
 int didi_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,

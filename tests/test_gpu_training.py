@@ -171,9 +171,29 @@ def test_split_both_equals_the_three_passes(dtype):
     seed, off = 1234567, 5 << 34
     xd = ops.dropout_add(x, None, 0.1, seed, off)
     assert 0.05 < float((xd == 0).float().mean()) < 0.15
+    u = torch.randn(1030, 776, generator=torch.Generator().manual_seed(4)).cuda()
+    (g_hi, g_lo), _, gcs = ops.split_both(x, dtype=dtype, transposed=False, gelu_u=u)  # of x * gelu'(u): act_backward on the read
+    (h_hi, h_lo), _, hcs = ops.split_both(ops.act_backward("gelu", x, u), dtype=dtype, transposed=False)
+    assert torch.equal(g_hi, h_hi) and torch.equal(g_lo, h_lo) and torch.equal(gcs, hcs)
     (d_hi, d_lo), (dt_hi, dt_lo), dcs = ops.split_both(x, dtype=dtype, drop=(0.1, seed, off))
     (e_hi, e_lo), (et_hi, et_lo), ecs = ops.split_both(xd, dtype=dtype)
     assert torch.equal(d_hi, e_hi) and torch.equal(d_lo, e_lo) and torch.equal(dt_hi, et_hi) and torch.equal(dt_lo, et_lo) and torch.equal(dcs, ecs)
+
+
+@pytest.mark.parametrize("H", [768, 1280, 128])
+def test_dropout_add_layernorm_equals_the_two_passes(H):
+    """didi_dropout_add_layernorm == didi_dropout_add followed by didi_layernorm, bit for bit (sum kept for the backward included)."""
+    from didi_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    x, r = torch.randn(1031, H, generator=g).cuda(), torch.randn(1031, H, generator=g).cuda()
+    gamma, beta = torch.randn(H, generator=g).cuda(), torch.randn(H, generator=g).cuda()
+    seed, off = 987654321, 7 << 34
+    for dtype in (torch.bfloat16, torch.float16):
+        hi, lo, y, s = ops.dropout_add_layernorm(x, r, 0.1, seed, off, gamma, beta, 1e-12, dtype=dtype)
+        s_want = ops.dropout_add(x, r, 0.1, seed, off)
+        hi_w, lo_w, y_w = ops.layernorm(s_want, gamma, beta, 1e-12, f32=True, dtype=dtype)
+        assert torch.equal(s, s_want) and torch.equal(y, y_w) and torch.equal(hi, hi_w) and torch.equal(lo, lo_w)
 
 
 def test_transpose_split_and_colsum():

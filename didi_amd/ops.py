@@ -35,11 +35,15 @@ def _f32c(t):
     return t
 
 
-def split(x, need_lo=True, dtype=torch.bfloat16):
-    """fp32 tensor -> (hi, lo) planes of the same shape, bf16 (default) or fp16."""
+def split(x, need_lo=True, dtype=torch.bfloat16, out=None):
+    """fp32 tensor -> (hi, lo) planes of the same shape, bf16 (default) or fp16.  ``out`` = (hi, lo): written in place."""
     x = _f32c(x)
-    hi = torch.empty_like(x, dtype=dtype)
-    lo = torch.empty_like(x, dtype=dtype) if need_lo else None
+    if out is not None:
+        hi, lo = out
+        assert hi.is_contiguous() and hi.dtype == dtype and hi.numel() == x.numel() and (lo is None or (lo.is_contiguous() and lo.dtype == dtype and lo.numel() == x.numel()))
+    else:
+        hi = torch.empty_like(x, dtype=dtype)
+        lo = torch.empty_like(x, dtype=dtype) if need_lo else None
     fn = lib.didi_split_fp16 if dtype == torch.float16 else lib.didi_split_bf16
     _lib.check(fn(x.data_ptr(), hi.data_ptr(), _lib.ptr(lo), x.numel(), _lib.current_stream()), "split")
     return hi, lo

@@ -46,13 +46,38 @@ DEFAULT_OPT = dict(weight_decay=0.01, scheduler="linear", lr=1e-4, warmup_steps=
 
 
 class _W:
-    """One Linear of the trained graph: fp32 master weight/bias (views into the trainer's parameter dict) + split planes."""
+    """One Linear of the trained graph: fp32 master weight/bias (views into the trainer's parameter dict) + split planes.
+    ``flat`` = (flat fp32 parameters, flat hi planes, flat lo planes, {name: offset}) and ``names`` = (weight names, bias names):
+    where the stacked tensors (q | k | v) lie back to back in the flat buffer, w, b, hi and lo are VIEWS of the flat buffers -- the
+    trainer re-splits all weights with one launch over the flat buffer and nothing is concatenated per step."""
 
-    def __init__(self, weights, biases, pd):
+    def __init__(self, weights, biases, pd, flat=None, names=None):
         self.weights, self.biases, self.pd = weights, biases, pd
-        self.refresh()
+        self.views = False
+        if flat is not None and names is not None:
+            fp, fh, fl, offs = flat
+
+            def span(ns, ts):  # (offset, numel) of tensors lying back to back in the flat buffer, else None
+                if any(n not in offs for n in ns):
+                    return None
+                o = [offs[n] for n in ns]
+                if any(o[i] + ts[i].numel() != o[i + 1] for i in range(len(ns) - 1)):
+                    return None
+                return o[0], sum(t_.numel() for t_ in ts)
+            sw = span(names[0], weights)
+            sb = span(names[1], biases) if biases is not None else (0, 0)
+            if sw is not None and sb is not None:
+                shape = (sum(w_.shape[0] for w_ in weights), weights[0].shape[1])
+                self.w = fp[sw[0]: sw[0] + sw[1]].view(shape)
+                self.hi, self.lo = fh[sw[0]: sw[0] + sw[1]].view(shape), fl[sw[0]: sw[0] + sw[1]].view(shape)
+                self.b = None if biases is None else fp[sb[0]: sb[0] + sb[1]]
+                self.views = True
+        if not self.views:
+            self.refresh()
 
     def refresh(self):
+        if self.views:  # the trainer's flat split keeps them current
+            return
         self.w = self.weights[0] if len(self.weights) == 1 else torch.cat(self.weights, 0)
         self.b = None if self.biases is None else (self.biases[0] if len(self.biases) == 1 else torch.cat(self.biases, 0))
         self.hi, self.lo = ops.split(self.w, dtype=self.pd)
@@ -102,8 +127,9 @@ class DiDiTrainer:
                 cv=p + "crossattention.self.value", co=p + "crossattention.output.dense", ln2=p + "crossattention.output.LayerNorm",
                 up=p + "intermediate.dense", down=p + "output.dense", ln3=p + "output.LayerNorm")
             self._layer_names.append(ln)
-            for v in ln.values():
-                names += [v + ".weight", v + ".bias"]
+            # stacked projections (q | k | v, cross k | v) back to back, weights then biases: their stack is a VIEW of the flat buffer
+            for grp in (("q", "k", "v"), ("o",), ("ln1",), ("cq",), ("ck", "cv"), ("co",), ("ln2",), ("up",), ("down",), ("ln3",)):
+                names += [ln[g] + ".weight" for g in grp] + [ln[g] + ".bias" for g in grp]
         # one flat fp32 buffer for all trainable parameters (and one each for AdamW's moments): the parameter dict holds views,
         # so the optimiser is ONE launch over the buffer and the gradient all-reduce walks contiguous buckets of its twin
         sizes = [state_dict[n].numel() for n in names]
@@ -123,22 +149,30 @@ class DiDiTrainer:
         view = lambda flat: {n: flat[self._offsets[n]: self._offsets[n] + P[n].numel()].view(P[n].shape) for n in names}  # noqa: E731
         self.m, self.v = view(self._flat_m), view(self._flat_v)
         self.step_count = 0
+        self._flat_hi = torch.empty(off, dtype=self._pd, device=self.device)  # planes of the whole flat buffer: one split per step
+        self._flat_lo = torch.empty_like(self._flat_hi)
+        ops.split(self._flat_p, dtype=self._pd, out=(self._flat_hi, self._flat_lo))
         self._build_linears()
 
     # ------------------------------------------------------------------ parameter views
     def _build_linears(self):
         P, pd = self.params, self._pd
-        W = lambda *ns: _W([P[n + ".weight"] for n in ns], [P[n + ".bias"] for n in ns], pd)  # noqa: E731
+        flat = (self._flat_p, self._flat_hi, self._flat_lo, self._offsets)
+        W = lambda *ns: _W([P[n + ".weight"] for n in ns], [P[n + ".bias"] for n in ns], pd, flat,  # noqa: E731
+                           ([n + ".weight" for n in ns], [n + ".bias" for n in ns]))
         self._lin = []
         for ln in self._layer_names:
             self._lin.append(dict(qkv=W(ln["q"], ln["k"], ln["v"]), o=W(ln["o"]), cq=W(ln["cq"]), ckv=W(ln["ck"], ln["cv"]), co=W(ln["co"]),
                                   up=W(ln["up"]), down=W(ln["down"])))
-        self._cls = _W([P["emb.weight" if self.cfg.tie_weights else "classifier.weight"]], None, pd)
+        cls_name = "emb.weight" if self.cfg.tie_weights else "classifier.weight"
+        self._cls = _W([P[cls_name]], None, pd, flat, ([cls_name], None))
         if self.cfg.has_adapter:
             self._ad0, self._ad2 = W("adapter.0"), W("adapter.2")
 
     def refresh_planes(self):
-        """Re-split every weight after the optimiser moved the fp32 masters."""
+        """Re-split every weight after the optimiser moved the fp32 masters: one launch over the flat buffer (the Linears hold views
+        of its planes); a Linear whose tensors do not lie back to back re-splits itself."""
+        ops.split(self._flat_p, dtype=self._pd, out=(self._flat_hi, self._flat_lo))
         for d in self._lin:
             for w in d.values():
                 w.refresh()

@@ -246,8 +246,9 @@ def main_training(args):
         "roofline": {"bound": "mfma", "kernel": "all GEMMs of the step (forward, dgrad, wgrad): whole-step figure, not a per-kernel one",
                      "achieved": round(gemm_flops / (elapsed / args.steps) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(gemm_flops / (elapsed / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                     "note": "algorithmic GEMM FLOPs of one step (3 x forward) / the whole step time; the backward's attention and elementwise "
-                             "kernels are correctness-level this round (DESIGN.md section 8)"},
+                     "note": "algorithmic GEMM FLOPs of one step (3 x forward) / the whole step time, attention, LayerNorm, dropout, the operand "
+                             "splits and the optimiser included; bf16x3 executes three MFMA products per algorithmic one "
+                             "(per kernel: DESIGN.md section 6, profiles/r03_train_kernel_stats_v7.csv)"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_training(cfg, sd, batches[0], tr)

@@ -693,11 +693,16 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
     const int Sq = p.Sq, Sk = p.Sk, D = p.D;
     const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int LD = D + 4, Sk4 = (Sk + 3) & ~3, LP = Sk4 + 4, L4 = LD / 4, D_4 = D / 4;
-    float* q = sm;                            // [Sq][LD]
-    float* k = q + Sq * LD;                   // [Sk][LD]
-    float* v = k + Sk * LD;                   // [Sk][LD]
-    float* g = v + Sk * LD;                   // dO [Sq][LD] (BWD only)
-    float* P = BWD ? g + Sq * LD : g;         // [Sq][LP]: scores -> probabilities (sign = dropout) -> dS
+    // The MFMA backward keeps THREE operand slots, not four: Q is needed by the scores and by dK (the last product), V only by dP in
+    // between, so V takes Q's slot once the scores are done (it waits in registers until then: 4 float4 per thread) and Q is fetched
+    // a second time (16 KB, L2) for dK.  70 KB instead of 87: TWO workgroups per CU, whose memory and compute phases overlap.
+    constexpr bool OV = MF && BWD;
+    float* q = sm;                                      // [Sq][LD]  (OV: max(Sq, Sk) rows; later V, then Q again)
+    float* k = q + (OV ? max(Sq, Sk) : Sq) * LD;        // [Sk][LD]
+    float* v = OV ? q : k + Sk * LD;                    // [Sk][LD]
+    float* g = OV ? k + Sk * LD : v + Sk * LD;          // dO [Sq][LD] (BWD only)
+    float* P = BWD ? g + Sq * LD : g;                   // [Sq][LP]: scores -> probabilities (sign = dropout) -> dS
+    float4 rv[OV ? NJ : 1];                             // OV: V between its load and the end of the scores
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     AT_STAMP(0);
     if constexpr (MF) {
@@ -707,7 +712,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
         // dropped: a workgroup walking three heads of its dialog with the next head's operands prefetched into registers
         // (backward 236 -> 262 us, forward 81 -> 113 us: a third of the workgroups, and the compiler keeps the loads next to their use).
         const int c = tid & 15, rb = tid >> 4;
-        float4 rq[6], rg[6], rk[NJ], rv[NJ];
+        float4 rq[6], rg[6], rk[NJ], rv_[OV ? 1 : NJ];
 #pragma unroll
         for (int j = 0; j < 6; ++j)
             if (rb + 16 * j < Sq) {
@@ -717,7 +722,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             rk[j] = ld4(p.K + ((size_t)b * Sk + rb + 16 * j) * p.ldk + h * 64 + c * 4);
-            rv[j] = ld4(p.V + ((size_t)b * Sk + rb + 16 * j) * p.ldv + h * 64 + c * 4);
+            (OV ? rv[j] : rv_[OV ? 0 : j]) = ld4(p.V + ((size_t)b * Sk + rb + 16 * j) * p.ldv + h * 64 + c * 4);
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j)
@@ -728,7 +733,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             *reinterpret_cast<float4*>(k + (rb + 16 * j) * LD + c * 4) = rk[j];
-            *reinterpret_cast<float4*>(v + (rb + 16 * j) * LD + c * 4) = rv[j];
+            if constexpr (!OV) *reinterpret_cast<float4*>(v + (rb + 16 * j) * LD + c * 4) = rv_[OV ? 0 : j];
         }
     } else {
     for (int i = tid; i < Sq * L4; i += 256) {
@@ -804,6 +809,11 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
     }
     __syncthreads();
     AT_STAMP(2);  // scores
+    if constexpr (OV) {  // Q's slot is free until dK: V moves in (visible after the softmax's barrier, first read by dP)
+        const int c = tid & 15, rb = tid >> 4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) *reinterpret_cast<float4*>(v + (rb + 16 * j) * LD + c * 4) = rv[j];
+    }
     // ---- row softmax: four lanes per row
     for (int r = tid >> 2; r < Sq; r += 64) {
         float* row = P + r * LP;
@@ -896,6 +906,14 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
         }
         __syncthreads();
         AT_STAMP(5);  // dV
+        // Q a second time, for dK: in flight under dP and dQ
+        float4 rq2[6];
+        {
+            const int c = tid & 15, rb = tid >> 4;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (rb + 16 * j < Sq) rq2[j] = ld4(p.Q + ((size_t)b * Sq + rb + 16 * j) * p.ldq + h * 64 + c * 4);
+        }
         // ---- dP = (dO V^T) o mask / keep; D_i = sum_c |P| dP (a wave owns whole rows: in-lane over the column tiles, then over the
         // 16 lanes of a row group); dS = |P| (dP - D) scale, back into P
         for (int i0 = 16 * wave; i0 < Sq; i0 += 64) {
@@ -927,6 +945,12 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
         }
         __syncthreads();
         AT_STAMP(6);  // dP -> dS
+        {  // V is done with: Q back into the slot (dQ below reads P and K only; the barrier after it publishes Q for dK)
+            const int c = tid & 15, rb = tid >> 4;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (rb + 16 * j < Sq) *reinterpret_cast<float4*>(q + (rb + 16 * j) * LD + c * 4) = rq2[j];
+        }
         // ---- dQ = dS K
         for (int i0 = 16 * wave; i0 < Sq; i0 += 64) {
             mf4 acc[4] = {mz, mz, mz, mz};
@@ -937,6 +961,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
                     for (int r4 = 0; r4 < 4; ++r4)
                         p.dQ[((size_t)b * Sq + i0 + 4 * lg + r4) * p.ldq + h * D + 16 * j + lr] = acc[j][r4];
         }
+        __syncthreads();
         AT_STAMP(7);  // dQ
         // ---- dK = dS^T Q
         for (int j0 = 16 * wave; j0 < Sk; j0 += 64) {
@@ -1066,7 +1091,10 @@ static int attention_train_launch(const didi_attn_train_args* a, bool bwd, void*
         DIDI_CHECK_ARG(reinterpret_cast<uintptr_t>(ptr) % 16 == 0);
     if (a->B == 0) return DIDI_OK;
     const int LD = a->D + 4, LP = ((a->Sk + 3) & ~3) + 4;
-    const size_t lds = sizeof(float) * ((size_t)(bwd ? 2 : 1) * a->Sq * LD + (size_t)2 * a->Sk * LD + (size_t)a->Sq * LP);
+    const bool mf = a->Sq % 16 == 0 && (a->Sk == 64 || a->Sk == 96) && a->D == 64;  // the fp32-MFMA form: the training shapes
+    const size_t lds = mf && bwd  // three operand slots (Q / V share one), dO, P
+                           ? sizeof(float) * ((size_t)(std::max(a->Sq, a->Sk) + a->Sk + a->Sq) * LD + (size_t)a->Sq * LP)
+                           : sizeof(float) * ((size_t)(bwd ? 2 : 1) * a->Sq * LD + (size_t)2 * a->Sk * LD + (size_t)a->Sq * LP);
     if (lds > 160 * 1024 - 256) return DIDI_ERR_UNSUPPORTED;
     static std::mutex mu;
     {
@@ -1081,7 +1109,6 @@ static int attention_train_launch(const didi_attn_train_args* a, bool bwd, void*
     if (!(p.scale > 0.f)) p.scale = 1.0f / sqrtf((float)a->D);
     const dim3 grid(a->heads, a->B);
     hipStream_t st = as_stream(stream);
-    const bool mf = a->Sq % 16 == 0 && (a->Sk == 64 || a->Sk == 96) && a->D == 64;  // the fp32-MFMA form: the training shapes
     if (mf && bwd) {
         if (a->Sk == 64) attention_train_kernel<4, true, true><<<grid, 256, lds, st>>>(p);
         else attention_train_kernel<6, true, true><<<grid, 256, lds, st>>>(p);

@@ -696,12 +696,14 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
     // The MFMA backward keeps THREE operand slots, not four: Q is needed by the scores and by dK (the last product), V only by dP in
     // between, so V takes Q's slot once the scores are done (it waits in registers until then: 4 float4 per thread) and Q is fetched
     // a second time (16 KB, L2) for dK.  70 KB instead of 87: TWO workgroups per CU, whose memory and compute phases overlap.
-    constexpr bool OV = MF && BWD;
+    // The MFMA forward at Sk = 64 (LP == LD) keeps no slot for P at all: a wave reads only ITS 16-row strip of Q for the scores and
+    // writes the same rows of P, in program order, so P lies on Q: 52 KB, three workgroups per CU.
+    constexpr bool OV = MF && BWD, OVF = MF && !BWD && NJ == 4;
     float* q = sm;                                      // [Sq][LD]  (OV: max(Sq, Sk) rows; later V, then Q again)
     float* k = q + (OV ? max(Sq, Sk) : Sq) * LD;        // [Sk][LD]
     float* v = OV ? q : k + Sk * LD;                    // [Sk][LD]
     float* g = OV ? k + Sk * LD : v + Sk * LD;          // dO [Sq][LD] (BWD only)
-    float* P = BWD ? g + Sq * LD : g;                   // [Sq][LP]: scores -> probabilities (sign = dropout) -> dS
+    float* P = OVF ? q : BWD ? g + Sq * LD : g;         // [Sq][LP]: scores -> probabilities (sign = dropout) -> dS
     float4 rv[OV ? NJ : 1];                             // OV: V between its load and the end of the scores
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     AT_STAMP(0);
@@ -1092,7 +1094,9 @@ static int attention_train_launch(const didi_attn_train_args* a, bool bwd, void*
     if (a->B == 0) return DIDI_OK;
     const int LD = a->D + 4, LP = ((a->Sk + 3) & ~3) + 4;
     const bool mf = a->Sq % 16 == 0 && (a->Sk == 64 || a->Sk == 96) && a->D == 64;  // the fp32-MFMA form: the training shapes
-    const size_t lds = mf && bwd  // three operand slots (Q / V share one), dO, P
+    const size_t lds = mf && !bwd && a->Sk == 64  // P lies on Q
+                           ? sizeof(float) * ((size_t)a->Sq + 2 * a->Sk) * LD
+                       : mf && bwd  // three operand slots (Q / V share one), dO, P
                            ? sizeof(float) * ((size_t)(std::max(a->Sq, a->Sk) + a->Sk + a->Sq) * LD + (size_t)a->Sq * LP)
                            : sizeof(float) * ((size_t)(bwd ? 2 : 1) * a->Sq * LD + (size_t)2 * a->Sk * LD + (size_t)a->Sq * LP);
     if (lds > 160 * 1024 - 256) return DIDI_ERR_UNSUPPORTED;

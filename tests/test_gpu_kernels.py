@@ -294,12 +294,13 @@ def test_gemm_split_k_on_the_big_tile(ops, M, N, K, precision):
     assert rel_l2(c, plain) <= 2e-6
 
 
-@pytest.mark.parametrize("M,N,K", [(16384, 768, 768), (8192, 2304, 768), (16384, 768, 3072), (16512, 1536, 768), (8192, 712, 3000)])
+@pytest.mark.parametrize("M,N,K", [(16384, 768, 768), (8192, 2304, 768), (16384, 768, 3072), (16512, 1536, 768), (8192, 712, 3000), (8192, 512, 192)])
 @pytest.mark.parametrize("precision", ["bf16x3", "fp16x2", "fp16x3"])
 def test_gemm_wgrad_from_untransposed_planes(ops, M, N, K, precision):
     """didi_gemm_wgrad: dW [N, K] = dC^T A read from the row-major planes of dC [M, N] and A [M, K] (transposing LDS reads; no
     transposed copy).  Against fp64 on the same rounded operands -- the decoder's five weight shapes at the training batch, a last
-    split shorter than the others (16512 rows), ragged last tiles on both sides (712 x 3000) -- and against the route it replaces
+    split shorter than the others (16512 rows), ragged last tiles on both sides (712 x 3000), the smallest output the form takes
+    (two tiles, 128 splits of two K-tiles) -- and against the route it replaces
     (transposed planes through didi_gemm_small) to summation-order rounding."""
     dc, a = rnd(M, N, seed=53, scale=0.02), rnd(M, K, seed=54)
     pd = PD[precision]
@@ -316,12 +317,13 @@ def test_gemm_wgrad_from_untransposed_planes(ops, M, N, K, precision):
     assert rel_l2(dW, old) <= 2e-6, rel_l2(dW, old)
 
 
-@pytest.mark.parametrize("M,N,K", [(16384, 768, 768), (8192, 2304, 768), (4096, 3072, 768), (8192, 768, 3072), (2100, 1536, 3000)])
+@pytest.mark.parametrize("M,N,K", [(16384, 768, 768), (8192, 2304, 768), (4096, 3072, 768), (8192, 768, 3072), (2100, 1536, 3000), (2048, 32, 192),
+                                   (2304, 64, 384)])
 @pytest.mark.parametrize("precision", ["bf16x3", "fp16x2", "fp16x3"])
 def test_gemm_dgrad_from_the_forward_weight_planes(ops, M, N, K, precision):
     """didi_gemm_dgrad: dA [M, K] = dC W + residual with W [N, K] read as the forward holds it (transposing LDS reads on the weight
     side only).  Against fp64 on the same rounded operands -- the decoder's four shapes, ragged last tiles on both sides (2100 x
-    3000) -- and against the route it replaces (didi_gemm on a transposed copy of W) to summation-order rounding."""
+    3000), contractions of one and two K-tiles -- and against the route it replaces (didi_gemm on a transposed copy of W) to summation-order rounding."""
     dc, w, r = rnd(M, N, seed=57, scale=0.02), rnd(N, K, seed=58, scale=0.05), rnd(M, K, seed=59)
     pd = PD[precision]
     assert ops.dgrad_supported(M, N, K, precision)

@@ -482,13 +482,19 @@ def main():
     if world > 1:  # RCCL builds its communicator on the first collective: keep that out of the timed region even with --warmup 0
         probe = torch.zeros((1, S + 1), dtype=torch.int32, device=dev)
         torch.distributed.all_gather_into_tensor(torch.empty((world, S + 1), dtype=torch.int32, device=dev), probe)
-    for _ in range(args.warmup):
+    def progress(what, i, n):  # stderr only (stdout carries the one JSON line): a 25-step run is minutes of silence otherwise
+        if rank == 0:
+            print(f"[bench] {what} {i + 1}/{n}", file=sys.stderr, flush=True)
+
+    for k in range(args.warmup):
         step()
+        progress("warm-up step", k, args.warmup)
     prof = GemmProf(calls=sorted(r[2] for r in regimes))
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
         out_ids, out_len = step(prof if k == 0 else None)
+        progress("timed step", k, args.steps)  # after the step's own id read-back: no extra synchronisation
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -482,9 +482,13 @@ def main():
     if world > 1:  # RCCL builds its communicator on the first collective: keep that out of the timed region even with --warmup 0
         probe = torch.zeros((1, S + 1), dtype=torch.int32, device=dev)
         torch.distributed.all_gather_into_tensor(torch.empty((world, S + 1), dtype=torch.int32, device=dev), probe)
+    t_prog = [time.perf_counter()]
+
     def progress(what, i, n):  # stderr only (stdout carries the one JSON line): a 25-step run is minutes of silence otherwise
         if rank == 0:
-            print(f"[bench] {what} {i + 1}/{n}", file=sys.stderr, flush=True)
+            now = time.perf_counter()
+            print(f"[bench] {what} {i + 1}/{n}: {now - t_prog[0]:.2f} s", file=sys.stderr, flush=True)  # host time since the last line
+            t_prog[0] = now
 
     for k in range(args.warmup):
         step()

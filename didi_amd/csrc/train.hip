@@ -693,18 +693,20 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
     const int Sq = p.Sq, Sk = p.Sk, D = p.D;
     const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int LD = D + 4, Sk4 = (Sk + 3) & ~3, LP = Sk4 + 4, L4 = LD / 4, D_4 = D / 4;
-    // The MFMA backward keeps THREE operand slots, not four: Q is needed by the scores and by dK (the last product), V only by dP in
-    // between, so V takes Q's slot once the scores are done (it waits in registers until then: 4 float4 per thread) and Q is fetched
-    // a second time (16 KB, L2) for dK.  70 KB instead of 87: TWO workgroups per CU, whose memory and compute phases overlap.
+    // The MFMA backward keeps TWO operand slots, not four: Q and K are needed by the scores and again only by the last two products
+    // (dK, dQ), dO and V only by dV and dP in between.  So dO and V wait in registers (4 float4 each per thread) until the scores are
+    // done, then take Q's and K's slots; Q and K are fetched a second time (32 KB, in flight under dP) for dQ / dK.  52 KB instead
+    // of 87: THREE workgroups per CU, whose memory and compute phases overlap (240 -> 181 us per launch; with three slots, two
+    // workgroups per CU: 197).
     // The MFMA forward at Sk = 64 (LP == LD) keeps no slot for P at all: a wave reads only ITS 16-row strip of Q for the scores and
     // writes the same rows of P, in program order, so P lies on Q: 52 KB, three workgroups per CU.
     constexpr bool OV = MF && BWD, OVF = MF && !BWD && NJ == 4;
     float* q = sm;                                      // [Sq][LD]  (OV: max(Sq, Sk) rows; later V, then Q again)
-    float* k = q + (OV ? max(Sq, Sk) : Sq) * LD;        // [Sk][LD]
-    float* v = OV ? q : k + Sk * LD;                    // [Sk][LD]
-    float* g = OV ? k + Sk * LD : v + Sk * LD;          // dO [Sq][LD] (BWD only)
-    float* P = OVF ? q : BWD ? g + Sq * LD : g;         // [Sq][LP]: scores -> probabilities (sign = dropout) -> dS
-    float4 rv[OV ? NJ : 1];                             // OV: V between its load and the end of the scores
+    float* k = q + (OV ? max(Sq, Sk) : Sq) * LD;        // [Sk][LD]  (OV: max(Sq, Sk) rows; V after the scores, K again for dQ)
+    float* v = OV ? k : k + Sk * LD;                    // [Sk][LD]
+    float* g = OV ? q : v + Sk * LD;                    // dO [Sq][LD] (BWD only; OV: in Q's slot after the scores, Q again for dK)
+    float* P = OVF ? q : OV ? k + max(Sq, Sk) * LD : BWD ? g + Sq * LD : g;  // [Sq][LP]: scores -> probabilities (sign = dropout) -> dS
+    float4 rv[OV ? NJ : 1], rgk[OV ? 6 : 1];            // OV: V and dO between their load and the end of the scores
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     AT_STAMP(0);
     if constexpr (MF) {
@@ -719,7 +721,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
         for (int j = 0; j < 6; ++j)
             if (rb + 16 * j < Sq) {
                 rq[j] = ld4(p.Q + ((size_t)b * Sq + rb + 16 * j) * p.ldq + h * 64 + c * 4);
-                if (BWD) rg[j] = ld4(p.dO + ((size_t)b * Sq + rb + 16 * j) * p.ldo + h * 64 + c * 4);
+                if (BWD) (OV ? rgk[OV ? j : 0] : rg[j]) = ld4(p.dO + ((size_t)b * Sq + rb + 16 * j) * p.ldo + h * 64 + c * 4);
             }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -730,7 +732,7 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
         for (int j = 0; j < 6; ++j)
             if (rb + 16 * j < Sq) {
                 *reinterpret_cast<float4*>(q + (rb + 16 * j) * LD + c * 4) = rq[j];
-                if (BWD) *reinterpret_cast<float4*>(g + (rb + 16 * j) * LD + c * 4) = rg[j];
+                if (BWD && !OV) *reinterpret_cast<float4*>(g + (rb + 16 * j) * LD + c * 4) = rg[j];
             }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -811,10 +813,13 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
     }
     __syncthreads();
     AT_STAMP(2);  // scores
-    if constexpr (OV) {  // Q's slot is free until dK: V moves in (visible after the softmax's barrier, first read by dP)
+    if constexpr (OV) {  // Q's and K's slots are free until dK / dQ: dO and V move in (visible after the softmax's barrier)
         const int c = tid & 15, rb = tid >> 4;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) *reinterpret_cast<float4*>(v + (rb + 16 * j) * LD + c * 4) = rv[j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (rb + 16 * j < Sq) *reinterpret_cast<float4*>(g + (rb + 16 * j) * LD + c * 4) = rgk[OV ? j : 0];
     }
     // ---- row softmax: four lanes per row
     for (int r = tid >> 2; r < Sq; r += 64) {
@@ -908,13 +913,15 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
         }
         __syncthreads();
         AT_STAMP(5);  // dV
-        // Q a second time, for dK: in flight under dP and dQ
-        float4 rq2[6];
+        // Q and K a second time, for dK and dQ: in flight under dP
+        float4 rq2[6], rk2[NJ];
         {
             const int c = tid & 15, rb = tid >> 4;
 #pragma unroll
             for (int j = 0; j < 6; ++j)
                 if (rb + 16 * j < Sq) rq2[j] = ld4(p.Q + ((size_t)b * Sq + rb + 16 * j) * p.ldq + h * 64 + c * 4);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rk2[j] = ld4(p.K + ((size_t)b * Sk + rb + 16 * j) * p.ldk + h * 64 + c * 4);
         }
         // ---- dP = (dO V^T) o mask / keep; D_i = sum_c |P| dP (a wave owns whole rows: in-lane over the column tiles, then over the
         // 16 lanes of a row group); dS = |P| (dP - D) scale, back into P
@@ -947,12 +954,15 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
         }
         __syncthreads();
         AT_STAMP(6);  // dP -> dS
-        {  // V is done with: Q back into the slot (dQ below reads P and K only; the barrier after it publishes Q for dK)
+        {  // dO and V are done with: Q and K back into their slots
             const int c = tid & 15, rb = tid >> 4;
 #pragma unroll
             for (int j = 0; j < 6; ++j)
                 if (rb + 16 * j < Sq) *reinterpret_cast<float4*>(q + (rb + 16 * j) * LD + c * 4) = rq2[j];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) *reinterpret_cast<float4*>(k + (rb + 16 * j) * LD + c * 4) = rk2[j];
         }
+        __syncthreads();
         // ---- dQ = dS K
         for (int i0 = 16 * wave; i0 < Sq; i0 += 64) {
             mf4 acc[4] = {mz, mz, mz, mz};
@@ -963,7 +973,6 @@ __global__ void __launch_bounds__(256) attention_train_kernel(didi_attn_train_ar
                     for (int r4 = 0; r4 < 4; ++r4)
                         p.dQ[((size_t)b * Sq + i0 + 4 * lg + r4) * p.ldq + h * D + 16 * j + lr] = acc[j][r4];
         }
-        __syncthreads();
         AT_STAMP(7);  // dQ
         // ---- dK = dS^T Q
         for (int j0 = 16 * wave; j0 < Sk; j0 += 64) {
@@ -1096,8 +1105,8 @@ static int attention_train_launch(const didi_attn_train_args* a, bool bwd, void*
     const bool mf = a->Sq % 16 == 0 && (a->Sk == 64 || a->Sk == 96) && a->D == 64;  // the fp32-MFMA form: the training shapes
     const size_t lds = mf && !bwd && a->Sk == 64  // P lies on Q
                            ? sizeof(float) * ((size_t)a->Sq + 2 * a->Sk) * LD
-                       : mf && bwd  // three operand slots (Q / V share one), dO, P
-                           ? sizeof(float) * ((size_t)(std::max(a->Sq, a->Sk) + a->Sk + a->Sq) * LD + (size_t)a->Sq * LP)
+                       : mf && bwd  // two operand slots (Q / dO, K / V), P
+                           ? sizeof(float) * ((size_t)2 * std::max(a->Sq, a->Sk) * LD + (size_t)a->Sq * LP)
                            : sizeof(float) * ((size_t)(bwd ? 2 : 1) * a->Sq * LD + (size_t)2 * a->Sk * LD + (size_t)a->Sq * LP);
     if (lds > 160 * 1024 - 256) return DIDI_ERR_UNSUPPORTED;
     static std::mutex mu;

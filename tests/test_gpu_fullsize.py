@@ -370,3 +370,46 @@ def test_id_agreement_config1_2208_positions():
         worst = max(rel_l2(a, b) for a, b in zip(tr, trace))
         print(f"\n[id agreement {precision}] ids differ {diff} of {want.numel()} ({100 - 100.0 * diff / want.numel():.3f} % agree)  max x_t rel-L2 {worst:.3e}")
         assert 1.0 - diff / want.numel() >= bar
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x2"])
+def test_training_gradients_at_the_bench_shape_equal_the_transposing_route(precision, monkeypatch):
+    """BASELINE configs[4]'s shape (12 x 768 decoder, 256 dialogs x 64 positions, dropout 0.1 / 0.1): every parameter gradient of one
+    step through the transposed-source GEMM forms (didi_gemm_wgrad / didi_gemm_dgrad on the planes as they lie, the backward of
+    dropout and GELU folded into the dC split) against the SAME step with those forms switched off (transposed copies through
+    didi_gemm, separate elementwise passes): same products, different summation order.  The gradient fixtures from the reference are
+    tiny models, which never take the transposed-source forms; this holds the composition at the shape bench.py times."""
+    from didi_amd import ops
+    from didi_amd.config import DiDiConfig
+    from didi_amd.synthetic import synthetic_batch, synthetic_state_dict
+    from didi_amd.trainer import DiDiTrainer
+
+    cfg = DiDiConfig(diffusion_steps=2000)
+    tr = DiDiTrainer(synthetic_state_dict(cfg, seed=1234), cfg, device="cuda", precision=precision, hidden_dropout=0.1, attention_dropout=0.1)
+    ids, mask = synthetic_batch(256, 64, cfg.vocab, seed=0xBADB01)
+    tids, tmask = synthetic_batch(256, 64, cfg.vocab, seed=0xBADB01 + 100)
+    ctx, tgt = _ctx(ids, mask), _ctx(tids, tmask)
+    used = {"wgrad": 0, "dgrad": 0}
+    wgrad, dgrad = ops.gemm_wgrad, ops.gemm_dgrad
+
+    def count(name, fn):
+        def f(*a, **kw):
+            used[name] += 1
+            return fn(*a, **kw)
+        return f
+
+    monkeypatch.setattr(ops, "gemm_wgrad", count("wgrad", wgrad))
+    monkeypatch.setattr(ops, "gemm_dgrad", count("dgrad", dgrad))
+    torch.manual_seed(7)  # the step draws its noise seed and timesteps from torch's generator
+    a = tr.forward_backward(ctx, tgt, dropout_seed=1234)
+    assert used["wgrad"] >= 7 * cfg.dec_layers and used["dgrad"] >= 6 * cfg.dec_layers, used
+    monkeypatch.setattr(ops, "wgrad_supported", lambda *a_: False)
+    monkeypatch.setattr(ops, "dgrad_supported", lambda *a_: False)
+    n_before = dict(used)
+    torch.manual_seed(7)
+    b = tr.forward_backward(ctx, tgt, dropout_seed=1234)
+    assert used == n_before, "the reference pass must not touch the transposed-source forms"
+    assert float(a["loss"]) == float(b["loss"])  # the forward is the same code either way
+    worst = max((rel_l2(a["grads"][k], b["grads"][k]), k) for k in b["grads"])
+    print(f"\n[configs4 gradients, {precision}] {len(b['grads'])} tensors, worst rel-L2 against the transposing route {worst[0]:.2e} ({worst[1]})")
+    assert set(a["grads"]) == set(b["grads"]) and worst[0] <= 2e-5, worst
